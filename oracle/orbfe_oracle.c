@@ -1,0 +1,676 @@
+/* orbfe_oracle.c -- CPU oracle for the ORB front-end hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * See orbfe_oracle.h for who may call this and for the "PARITY UNPINNED" statement.
+ * Every function cites the reference lines (relative to /root/reference) it restates.
+ * The restatement is deliberately literal (thread ids, warps, shuffles, shared-memory
+ * scans are simulated as written) so that it is an independent check of the closed forms
+ * the HIP kernels use.  Quirk numbers Qn refer to SURVEY.md Appendix A.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fPIC -shared (oracle/Makefile).  -ffp-contract=off is
+ * REQUIRED: include/orbfe_math.h must see no fused multiply-add.
+ */
+#include "orbfe_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/orbfe_math.h"
+#include "../include/orbfe_pattern.h"
+
+#define WARP 32 /* CUDA_WARP_SIZE, src/cuda_common.h:57-59 */
+
+static const int8_t g_pattern[ORBFE_PATTERN_TESTS * 4] = {ORBFE_PATTERN_VALUES};
+
+const int8_t *oracle_pattern(void) { return g_pattern; }
+float oracle_atan2f(float y, float x) { return orbfe_atan2f(y, x); }
+void oracle_sincosf(float x, float *s, float *c) { orbfe_sincosf(x, s, c); }
+int oracle_has_arc(uint32_t mask, int arc) { return orbfe_has_arc(mask, arc); }
+
+/* ------------------------------------------------------------------------------------
+ * a2  gaussian_blur_3x3        src/cuda/gaussian_blur_3x3.cu:15-53 (kernel), :55-73 (host)
+ * One 32-lane warp per 32 columns of one row; horizontal taps come from __shfl_up/_down
+ * inside the warp, so lane 0 has no left and lane 31 no right neighbour and gets its own
+ * value back (Q2).  Rows 0, h-2, h-1 are never written (:22-23) -> decided 0 (Q1).
+ * If w % 32 != 0 the last active lane shuffles from an exited lane: decided own value (Q2).
+ * ------------------------------------------------------------------------------------ */
+void oracle_gaussian_blur_3x3(uint8_t *blurred, int blurred_pitch, const uint8_t *image,
+                              int image_pitch, int w, int h)
+{
+    for (int y = 0; y < h; y++) {
+        uint8_t *out = blurred + (size_t)y * blurred_pitch;
+        if (y == 0 || y >= h - 2) { /* :22 */
+            memset(out, 0, (size_t)w);
+            continue;
+        }
+        for (int x = 0; x < w; x++) {
+            int lane = x & (WARP - 1);
+            int xl = (lane == 0) ? x : x - 1;                  /* __shfl_up, delta 1  */
+            int xr = (lane == WARP - 1 || x == w - 1) ? x : x + 1; /* __shfl_down, delta 1 */
+            const uint8_t *ra = image + (size_t)(y - 1) * image_pitch;
+            const uint8_t *rb = image + (size_t)y * image_pitch;
+            const uint8_t *rc = image + (size_t)(y + 1) * image_pitch;
+            int a = ra[x], b = rb[x], c = rc[x];
+            int blur_sum = 0;
+            blur_sum += a * 2; /* :37-45 */
+            blur_sum += b * 4;
+            blur_sum += c * 2;
+            blur_sum += ra[xl];
+            blur_sum += ra[xr];
+            blur_sum += rb[xl] * 2;
+            blur_sum += rb[xr] * 2;
+            blur_sum += rc[xl];
+            blur_sum += rc[xr];
+            out[x] = (uint8_t)floor((double)((float)blur_sum / 16.0f) + 0.5); /* :49 */
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * a3  image_halfsample_gpu_kernel / pyramid_create_levels   src/cuda/pyramid.cu:6-29, :31-84
+ * dst(x,y) = (s(2x,2y)+s(2x+1,2y)+s(2x,2y+1)+s(2x+1,2y+1)) >> 2.  The vector width N only
+ * changes how many outputs one thread writes, not their values (:37-40).
+ * ------------------------------------------------------------------------------------ */
+void oracle_halfsample(const uint8_t *src, int src_pitch, uint8_t *dst, int dst_pitch,
+                       int dst_w, int dst_h)
+{
+    for (int y = 0; y < dst_h; y++) {
+        const uint8_t *t = src + (size_t)(2 * y) * src_pitch;
+        const uint8_t *b = t + src_pitch;
+        uint8_t *o = dst + (size_t)y * dst_pitch;
+        for (int x = 0; x < dst_w; x++)
+            o[x] = (uint8_t)(((unsigned)t[2 * x] + (unsigned)t[2 * x + 1] + (unsigned)b[2 * x] +
+                              (unsigned)b[2 * x + 1]) >> 2); /* :26 */
+    }
+}
+
+void oracle_pyramid_create_levels(const oracle_level *lv, int n_levels)
+{
+    for (int i = 1; i < n_levels; i++) /* :33 */
+        oracle_halfsample(lv[i - 1].image, lv[i - 1].image_pitch, lv[i].image, lv[i].image_pitch,
+                          lv[i].width, lv[i].height);
+}
+
+/* ------------------------------------------------------------------------------------
+ * a4  fast_gpu_is_corner / fast_gpu_calculate_lut     src/cuda/fast.cu:11-32, :34-39, :292-302
+ * ------------------------------------------------------------------------------------ */
+static int clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; } /* CUDA __clz(0) = 32 */
+
+int oracle_fast_is_corner(uint32_t address, int min_arc_length)
+{
+    int ones = __builtin_popcount(address);
+    if (ones < min_arc_length) return 0; /* :15-18 */
+    uint32_t address_dup = address | (address << 16);
+    while (ones > 0) {
+        int sh = clz32(address_dup);
+        address_dup = sh >= 32 ? 0u : address_dup << sh; /* shift out the high order zeros */
+        int lones = clz32(~address_dup);                 /* count the leading ones */
+        if (lones >= min_arc_length) return 1;
+        address_dup = lones >= 32 ? 0u : address_dup << lones;
+        ones -= lones;
+    }
+    return 0;
+}
+
+void oracle_fast_calculate_lut(uint8_t *lut, int min_arc)
+{
+    for (uint32_t m = 0; m < 65536u; m++) lut[m] = (uint8_t)oracle_fast_is_corner(m, min_arc);
+}
+
+/* ------------------------------------------------------------------------------------
+ * a5  fast_gpu_calc_corner_response_kernel<SUM_OF_ABS_DIFF_ON_ARC>
+ *     src/cuda/fast.cu:150-287; ring offsets :41-96; prechecks :98-124.
+ * The reference's `min_arc_length` kernel argument is unused and the score enum is the
+ * one selected by defines.h:9 (Q4).  All values are small integers held in floats.
+ * ------------------------------------------------------------------------------------ */
+static int ring_offset(int i, int pitch)
+{
+    switch (i) { /* :62-95 */
+    case 0: return 3 * pitch;
+    case 1: return 3 * pitch - 1;
+    case 2: return 2 * pitch - 2;
+    case 3: return pitch - 3;
+    case 4: return -3;
+    case 5: return -pitch - 3;
+    case 6: return -2 * pitch - 2;
+    case 7: return -3 * pitch - 1;
+    case 8: return -3 * pitch;
+    case 9: return -3 * pitch + 1;
+    case 10: return -2 * pitch + 2;
+    case 11: return -pitch + 3;
+    case 12: return 3;
+    case 13: return pitch + 3;
+    case 14: return 2 * pitch + 2;
+    default: return 3 * pitch + 1;
+    }
+}
+
+static int sgnbit(float v) { return signbit(v) ? 1 : 0; }
+
+void oracle_fast_calc_corner_response(int w, int h, int pitch, const uint8_t *img, int hb,
+                                      int vb, const uint8_t *lut, float threshold,
+                                      int resp_pitch_elems, float *resp)
+{
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            float *out = resp + (size_t)y * resp_pitch_elems + x;
+            *out = 0.0f; /* :169 */
+            if (!(x >= hb && y >= vb && x < w - hb && y < h - vb)) continue;
+            const uint8_t *p = img + (size_t)y * pitch + x;
+            const float c = (float)*p;
+            const float ct = c + threshold;
+            const float c_t = c - threshold;
+            /* prechecks :98-124 */
+            {
+                float px0 = (float)p[ring_offset(4, pitch)];
+                float px1 = (float)p[ring_offset(12, pitch)];
+                if ((sgnbit(px0 - c_t) | sgnbit(px1 - c_t) | sgnbit(ct - px0) |
+                     sgnbit(ct - px1)) == 0)
+                    continue;
+                px0 = (float)p[ring_offset(0, pitch)];
+                px1 = (float)p[ring_offset(8, pitch)];
+                if ((sgnbit(px0 - c_t) | sgnbit(px1 - c_t) | sgnbit(ct - px0) |
+                     sgnbit(ct - px1)) == 0)
+                    continue;
+            }
+            float px[16];
+            unsigned dark = 0, bright = 0;
+            for (int i = 0; i < 16; i++) { /* :214-222 */
+                px[i] = (float)p[ring_offset(i, pitch)];
+                dark += sgnbit(px[i] - c_t) ? (1u << i) : 0u;
+                bright += sgnbit(ct - px[i]) ? (1u << i) : 0u;
+            }
+            if (lut[dark] || lut[bright]) { /* :225 */
+                float response_bright = 0.0f, response_dark = 0.0f;
+                for (int i = 0; i < 16; i++) { /* :248-253 */
+                    float absdiff = fabsf(px[i] - c) - threshold;
+                    response_dark += (dark & (1u << i)) ? absdiff : 0.0f;
+                    response_bright += (bright & (1u << i)) ? absdiff : 0.0f;
+                }
+                *out = fmaxf(response_bright, response_dark); /* :254 */
+            }
+        }
+}
+
+/* ------------------------------------------------------------------------------------
+ * a6  detector_base_gpu_grid_nms_kernel<true> / grid_nms     src/cuda/nms.cu:86-254, :256-296
+ * Literal simulation of one thread block per cell: per-thread column scan with the
+ * copysign suppression trick, 32-lane __shfl_down tournament, shared-memory scan by
+ * thread (0,0), compare-and-replace into d_score/d_pos/d_level.
+ * Decisions: lanes that do not exist in a partial warp never win (Q6); level 0 also
+ * resets pos and level so that empty cells read (0,0)/0 (Q5).  `cell` generalises the
+ * reference's fixed 32 (EXT ii); levels with (cell >> level) == 0 are skipped (EXT i; the
+ * reference divides by zero there, nms.cu:273).
+ * ------------------------------------------------------------------------------------ */
+static int nms_offset(int i, int pitch)
+{
+    switch (i) { /* :58-84, spiral N,NE,E,SE,S,SW,W,NW */
+    case 0: return -pitch;
+    case 1: return -pitch + 1;
+    case 2: return 1;
+    case 3: return pitch + 1;
+    case 4: return pitch;
+    case 5: return pitch - 1;
+    case 6: return -1;
+    default: return -pitch - 1;
+    }
+}
+
+static void nms_block(int level, int bx_idx, int by_idx, int grid_w, int image_width,
+                      int image_height, int cell_w, int cell_h, int bdx, int bdy,
+                      int response_pitch_elements, const float *d_response, float *d_pos,
+                      float *d_score, int32_t *d_level)
+{
+    const int hb = 3, vb = 3; /* nms.cu:285-286 */
+    const int nthreads = bdx * bdy;
+    const int warp_cnt = (nthreads + 31) >> 5;
+    float t_resp[128], t_x[128], t_y[128];
+    const int cell_id = grid_w * by_idx + bx_idx;
+
+    for (int ty = 0; ty < bdy; ty++)
+        for (int tx = 0; tx < bdx; tx++) {
+            const int x = cell_w * bx_idx + tx;
+            const int y = cell_h * by_idx + ty;
+            const int thread_id = tx + bdx * ty;
+            float max_x = (float)x, max_y = 0.f, max_resp = 0.0f;
+            if (x < image_width && y < image_height) {
+                if (tx == 0 && ty == 0 && level == 0) { /* :116-123 (+ Q5 reset) */
+                    d_score[cell_id] = 0.0f;
+                    d_pos[2 * cell_id] = 0.0f;
+                    d_pos[2 * cell_id + 1] = 0.0f;
+                    d_level[cell_id] = 0;
+                }
+                int max_y_tmp = 0;
+                int image_width_m_border = image_width - hb;
+                int image_height_m_border = image_height - vb;
+                if (x >= hb && x < image_width_m_border) {
+                    int cell_top_to_border = vb - (cell_h * by_idx);
+                    int y_offset = cell_top_to_border > 0 ? cell_top_to_border : 0;
+                    int gy = y + y_offset;
+                    int box_line = ty + y_offset;
+                    for (; (box_line < cell_h) && (gy < image_height_m_border);
+                         box_line += bdy, gy += bdy) {
+                        const float *rp = d_response + (size_t)gy * response_pitch_elements + x;
+                        float center_value = rp[0];
+                        for (int i = 0; i < 8; i++) { /* :161-185 */
+                            int j = nms_offset(i, response_pitch_elements);
+                            center_value *=
+                                -0.5f * (-1.0f + copysignf(1.0f, rp[j] - center_value));
+                            if (center_value == 0.0f) break;
+                        }
+                        if (center_value > max_resp) { /* :188 */
+                            max_resp = center_value;
+                            max_y_tmp = gy;
+                        }
+                    }
+                }
+                max_y = (float)max_y_tmp;
+            }
+            t_resp[thread_id] = max_resp;
+            t_x[thread_id] = max_x;
+            t_y[thread_id] = max_y;
+        }
+
+    /* warp tournament :201-212 -- all lanes read before any lane writes */
+    for (int offset = WARP / 2; offset > 0; offset /= 2) {
+        float n_resp[128], n_x[128], n_y[128];
+        for (int t = 0; t < nthreads; t++) {
+            int lane = t & 31;
+            int src = t + offset;
+            if (lane + offset < WARP && src < nthreads) {
+                n_resp[t] = t_resp[src];
+                n_x[t] = t_x[src];
+                n_y[t] = t_y[src];
+            } else { /* out of warp: own value; non-existent lane: never wins (Q6) */
+                n_resp[t] = t_resp[t];
+                n_x[t] = t_x[t];
+                n_y[t] = t_y[t];
+            }
+        }
+        for (int t = 0; t < nthreads; t++)
+            if (n_resp[t] > t_resp[t]) {
+                t_resp[t] = n_resp[t];
+                t_x[t] = n_x[t];
+                t_y[t] = n_y[t];
+            }
+    }
+    /* shared memory, lane 0 of each warp :218-227; thread (0,0) scans :230-244 */
+    float max_resp = t_resp[0], max_x = t_x[0], max_y = t_y[0];
+    for (int i = 1; i < warp_cnt; i++) {
+        int t = i * 32;
+        if (t_resp[t] > max_resp) {
+            max_resp = t_resp[t];
+            max_x = t_x[t];
+            max_y = t_y[t];
+        }
+    }
+    float scale = (float)(1 << level);
+    if (d_score[cell_id] < max_resp) { /* :246-252 */
+        d_score[cell_id] = max_resp;
+        d_pos[2 * cell_id] = max_x * scale;
+        d_pos[2 * cell_id + 1] = max_y * scale;
+        d_level[cell_id] = level;
+    }
+}
+
+static int imin(int a, int b) { return a < b ? a : b; }
+static int imax(int a, int b) { return a > b ? a : b; }
+
+void oracle_grid_nms(const oracle_level *lv, int n_levels, int cell, float *pos, float *score,
+                     int32_t *level_out)
+{
+    /* :262-263 with 32 -> cell */
+    const int hcells = (lv[0].width % cell == 0) ? lv[0].width / cell : lv[0].width / cell + 1;
+    const int vcells = (lv[0].height % cell == 0) ? lv[0].height / cell : lv[0].height / cell + 1;
+    for (int level = 0; level < n_levels; level++) {
+        const int cw = cell >> level, ch = cell >> level; /* :266-267 */
+        if (cw == 0) break;                              /* EXT i */
+        const int bdx = cw;
+        const int bdy = imax(1, imin(128 / cw, ch)); /* :272-273 */
+        for (int by = 0; by < vcells; by++)
+            for (int bx = 0; bx < hcells; bx++)
+                nms_block(level, bx, by, hcells, lv[level].width, lv[level].height, cw, ch, bdx,
+                          bdy, lv[level].response_pitch, lv[level].response, pos, score,
+                          level_out);
+    }
+}
+
+/* a7  detect   src/cuda/fast.cu:374-407 */
+void oracle_detect(const oracle_level *lv, int n_levels, int cell, const uint8_t *lut,
+                   float threshold, float *pos, float *score, int32_t *level_out)
+{
+    for (int l = 0; l < n_levels; l++)
+        oracle_fast_calc_corner_response(lv[l].width, lv[l].height, lv[l].image_pitch,
+                                         lv[l].image, 3, 3, lut, threshold,
+                                         lv[l].response_pitch, lv[l].response);
+    oracle_grid_nms(lv, n_levels, cell, pos, score, level_out);
+}
+
+/* ------------------------------------------------------------------------------------
+ * a8  compute_fast_angle_kernel     src/cuda/orb.cu:77-142
+ * 32 threads = 31 patch columns (+1 idle); per-thread float partial sums (exact: every
+ * partial and the total are integers below 2^24), 32-lane __shfl_down sum, atan2f.
+ * Empty cells (score == 0): angle 0 (Q5).  `score` may be NULL (= compute all).
+ * ------------------------------------------------------------------------------------ */
+void oracle_compute_fast_angle(float *angle, const float *pos, const float *score,
+                               const uint8_t *image, int image_pitch, int image_width,
+                               int image_height, int n)
+{
+    for (int idx = 0; idx < n; idx++) {
+        if (score && !(score[idx] > 0.0f)) {
+            angle[idx] = 0.0f;
+            continue;
+        }
+        int k_x = (int)floor((double)pos[2 * idx] + 0.5);
+        int k_y = (int)floor((double)pos[2 * idx + 1] + 0.5);
+        int r2 = 15 * 15;
+        float m10_t[32], m01_t[32];
+        for (int tid = 0; tid < 32; tid++) {
+            float m10 = 0, m01 = 0;
+            if (tid < 31) { /* :94-102 */
+                int mult_dx = tid - 15;
+                int tdx = tid + k_x - 15;
+                if (tdx > 0 && tdx < image_width)
+                    m10 = (float)(mult_dx * image[(size_t)k_y * image_pitch + tdx]);
+            }
+            for (int dy = 1; dy < 16; dy++) { /* :104-126 */
+                int dx = (int)floor((double)sqrtf((float)r2 - (float)(dy * dy)) + 0.5);
+                if (tid > 14 - dx && tid < 16 + dx) {
+                    int mult_dx = tid - 15;
+                    int tdx = k_x + tid - 15;
+                    if (k_y - dy > 0 && tdx > 0 && tdx < image_width) {
+                        float i = image[(size_t)(k_y - dy) * image_pitch + tdx];
+                        m01 -= dy * i;
+                        m10 += mult_dx * i;
+                    }
+                    if (k_y + dy < image_height && tdx > 0 && tdx < image_width) {
+                        float i = image[(size_t)(k_y + dy) * image_pitch + tdx];
+                        m01 += dy * i;
+                        m10 += mult_dx * i;
+                    }
+                }
+            }
+            m10_t[tid] = m10;
+            m01_t[tid] = m01;
+        }
+        for (int offset = 16; offset > 0; offset /= 2) /* :130-134 */
+            for (int t = 0; t + offset < 32; t++) {
+                /* lanes with t+offset >= 32 receive their own value; lane 0 never depends on
+                 * them, and only lane 0 is read (:138). */
+                if (t < offset) {
+                    m01_t[t] += m01_t[t + offset];
+                    m10_t[t] += m10_t[t + offset];
+                }
+            }
+        angle[idx] = orbfe_atan2f(m01_t[0], m10_t[0]); /* :140 */
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * a9  calc_orb_kernel (+ GET_VALUE)   src/cuda/orb.cu:12-14, :17-75
+ * a10 compress_descriptors_kernel     src/cuda/orb.cu:145-169
+ * 32 threads = 32 descriptor bytes; pattern viewed as 512 int2 points, thread t uses
+ * points 16t .. 16t+15 (:40).  Products and the single add/sub are separate f32
+ * operations (no contraction, Q7 decision); __float2int_rn = round half to even.
+ * EXT v (angle_in_radians): the stored angle is used directly and the border guard grows
+ * from 17 to 19 because the rotated pattern then reaches 18 px.
+ * ------------------------------------------------------------------------------------ */
+void oracle_calc_orb(const float *d_angle, const float *d_pos, uint8_t *desc_tmp,
+                     uint32_t *desc32, const uint8_t *image, int image_pitch, int image_width,
+                     int image_height, int n, int angle_in_radians)
+{
+    for (int id = 0; id < n; id++) {
+        uint8_t *desc = desc_tmp + (size_t)id * 32;
+        short lx = (short)d_pos[2 * id], ly = (short)d_pos[2 * id + 1]; /* :32 */
+        int zero;
+        if (!angle_in_radians)
+            zero = (lx < 17 || lx > image_width - 17 || ly < 17 || ly > image_height - 17);
+        else
+            zero = (lx < 19 || lx > image_width - 20 || ly < 19 || ly > image_height - 20);
+        if (zero) {
+            memset(desc, 0, 32); /* :34-38 */
+        } else {
+            const float factorPI = (float)(3.141592654f / 180.f); /* :42 */
+            float ang = angle_in_radians ? d_angle[id] : d_angle[id] * factorPI;
+            float a, b;
+            orbfe_sincosf(ang, &b, &a); /* a = cos, b = sin :45-46 */
+            for (int tid = 0; tid < 32; tid++) {
+                const int8_t *pt = g_pattern + 2 * (16 * tid); /* int2 index 16*tid */
+                int val = 0;
+                for (int k = 0; k < 8; k++) {
+                    int t[2];
+                    for (int e = 0; e < 2; e++) {
+                        float pxf = (float)pt[2 * (2 * k + e)];
+                        float pyf = (float)pt[2 * (2 * k + e) + 1];
+                        float m1 = pxf * b, m2 = pyf * a, m3 = pxf * a, m4 = pyf * b;
+                        int row = ly + orbfe_rn_int(m1 + m2);
+                        int col = lx + orbfe_rn_int(m3 - m4);
+                        t[e] = image[(size_t)row * image_pitch + col];
+                    }
+                    val |= (t[0] < t[1]) << k;
+                }
+                desc[tid] = (uint8_t)val;
+            }
+        }
+        if (desc32) { /* :149-167 */
+            uint32_t d = 0;
+            for (int i = 0; i < 32; i++)
+                if (desc[i] == 1) d |= (1u << i);
+            desc32[id] = d;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * a11  kernel_match_keypoints   src/cuda/post_processing.cu:92-200 (host :234-341)
+ * Blocks of 32 threads over prev; curr scanned in shared-memory tiles of 32; in a tile of
+ * m entries thread tid visits j = (s + tid) % m for s = 0..m-1, only if tid < m (Q8).
+ * Decisions: the tile is taken as fully loaded even when the last prev block has fewer
+ * than 32 live threads (the reference then reads stale shared memory: UB, Q9); output is
+ * match_idx[i] (curr index or -1) instead of atomically compacted lists; returns the count.
+ * pos_prev is the reprojected prev position (kernel_reproject_prev_points, out of scope).
+ * ------------------------------------------------------------------------------------ */
+int oracle_match_keypoints(const float *pos_prev, const uint32_t *desc_prev, int n_prev,
+                           const float *pos_curr, const uint32_t *desc_curr, int n_curr,
+                           int max_pixel_distance, int max_hamming_distance,
+                           int32_t *match_idx)
+{
+    int matched = 0;
+    for (int idx = 0; idx < n_prev; idx++) {
+        const int tid = idx & 31;
+        int pair_idx = 0, is_matched = 0;
+        int hamming_distance_curr = 9999999;
+        const uint32_t descriptor = desc_prev[idx];
+        const float ppx = pos_prev[2 * idx], ppy = pos_prev[2 * idx + 1];
+        for (int i = 0; i < n_curr; i += WARP) {
+            int max_j_loop = WARP;
+            if (i + WARP >= n_curr) max_j_loop = n_curr - i;
+            for (int j = 0; j < max_j_loop; j++) {
+                if (tid < max_j_loop) {
+                    int j_idx = (j + tid) % max_j_loop;
+                    const float cx = pos_curr[2 * (i + j_idx)], cy = pos_curr[2 * (i + j_idx) + 1];
+                    if (fabsf(ppx - cx) <= (float)max_pixel_distance &&
+                        fabsf(ppy - cy) <= (float)max_pixel_distance) {
+                        int hd = __builtin_popcount(descriptor ^ desc_curr[i + j_idx]);
+                        if (hd < max_hamming_distance && hd < hamming_distance_curr) {
+                            hamming_distance_curr = hd;
+                            is_matched = 1;
+                            pair_idx = i + j_idx;
+                        }
+                    }
+                }
+            }
+        }
+        match_idx[idx] = is_matched ? pair_idx : -1;
+        matched += is_matched;
+    }
+    return matched;
+}
+
+/* EXT C.9: brute-force 256-bit Hamming, lexicographic (dist, idx) minimum. */
+void oracle_match256(const uint8_t *descA, const float *posA, int nA, const uint8_t *descB,
+                     const float *posB, int nB, int window, int max_dist, int32_t *idx,
+                     int32_t *dist)
+{
+    for (int i = 0; i < nA; i++) {
+        int best = 1 << 30, best_j = -1;
+        for (int j = 0; j < nB; j++) {
+            if (window >= 0) {
+                if (fabsf(posA[2 * i] - posB[2 * j]) > (float)window ||
+                    fabsf(posA[2 * i + 1] - posB[2 * j + 1]) > (float)window)
+                    continue;
+            }
+            int d = 0;
+            for (int b = 0; b < 32; b++)
+                d += __builtin_popcount((unsigned)(descA[32 * i + b] ^ descB[32 * j + b]));
+            if (d < best) {
+                best = d;
+                best_j = j;
+            }
+        }
+        if (best_j >= 0 && best <= max_dist) {
+            idx[i] = best_j;
+            dist[i] = best;
+        } else {
+            idx[i] = -1;
+            dist[i] = -1;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * Whole pipeline on one frame, in the call order of
+ * src/SlamGpuPipeline/buildStream.cpp:424-460 (blur -> levels -> detect -> angle -> orb).
+ * Level sizes halve with floor (buildStream.cpp:312-336).
+ * ------------------------------------------------------------------------------------ */
+int oracle_num_cells(const oracle_config *cfg)
+{
+    int gc = (cfg->width + cfg->cell - 1) / cfg->cell; /* buildStream.cpp:233-235 */
+    int gr = (cfg->height + cfg->cell - 1) / cfg->cell;
+    return gc * gr;
+}
+
+size_t oracle_level_dims(const oracle_config *cfg, int level, int *w, int *h)
+{
+    int ww = cfg->width, hh = cfg->height;
+    for (int i = 0; i < level; i++) {
+        ww /= 2;
+        hh /= 2;
+    }
+    if (w) *w = ww;
+    if (h) *h = hh;
+    return (size_t)ww * hh;
+}
+
+typedef struct {
+    float score;
+    int cell;
+} sel_t;
+
+static int sel_cmp(const void *a, const void *b)
+{
+    const sel_t *x = (const sel_t *)a, *y = (const sel_t *)b;
+    if (x->score != y->score) return x->score > y->score ? -1 : 1; /* score desc */
+    return x->cell - y->cell;                                      /* cell asc  */
+}
+
+int oracle_extract_frame(const oracle_config *cfg, const uint8_t *gray, int gray_pitch,
+                         uint8_t **pyr_out, float *pos_o, float *score_o, int32_t *level_o,
+                         float *angle_o, uint8_t *desc_o, uint32_t *desc32_o,
+                         oracle_keypoint *records)
+{
+    const int L = cfg->levels, K = oracle_num_cells(cfg);
+    oracle_level *lv = (oracle_level *)calloc((size_t)L, sizeof(oracle_level));
+    for (int l = 0; l < L; l++) {
+        int w, h;
+        oracle_level_dims(cfg, l, &w, &h);
+        lv[l].width = w;
+        lv[l].height = h;
+        lv[l].image_pitch = w > 0 ? w : 1;
+        lv[l].response_pitch = w > 0 ? w : 1;
+        lv[l].image = (uint8_t *)calloc((size_t)(w * h) + 1, 1);
+        lv[l].response = (float *)calloc((size_t)(w * h) + 1, sizeof(float));
+    }
+    uint8_t *lut = (uint8_t *)malloc(65536);
+    float *pos = (float *)calloc((size_t)K * 2, sizeof(float));
+    float *score = (float *)calloc((size_t)K, sizeof(float));
+    int32_t *level = (int32_t *)calloc((size_t)K, sizeof(int32_t));
+    float *angle = (float *)calloc((size_t)K, sizeof(float));
+    uint8_t *desc = (uint8_t *)calloc((size_t)K * 32, 1);
+    uint32_t *desc32 = (uint32_t *)calloc((size_t)K, sizeof(uint32_t));
+    float *sel_score = (float *)calloc((size_t)K, sizeof(float));
+
+    oracle_gaussian_blur_3x3(lv[0].image, lv[0].image_pitch, gray, gray_pitch, cfg->width,
+                             cfg->height);
+    oracle_pyramid_create_levels(lv, L);
+    oracle_fast_calculate_lut(lut, cfg->min_arc);
+    /* detection only on levels whose cell is >= 1 px (EXT i) and that hold a pixel */
+    int Ld = 0;
+    while (Ld < L && (cfg->cell >> Ld) > 0 && lv[Ld].width > 0 && lv[Ld].height > 0) Ld++;
+    oracle_detect(lv, Ld, cfg->cell, lut, cfg->fast_threshold, pos, score, level);
+
+    /* selection: every non-empty cell, or the top-N by (score desc, cell asc) (EXT ii) */
+    memcpy(sel_score, score, (size_t)K * sizeof(float));
+    if (cfg->max_features > 0) {
+        sel_t *s = (sel_t *)malloc((size_t)K * sizeof(sel_t));
+        int n = 0;
+        for (int k = 0; k < K; k++)
+            if (score[k] > 0.0f) {
+                s[n].score = score[k];
+                s[n].cell = k;
+                n++;
+            }
+        qsort(s, (size_t)n, sizeof(sel_t), sel_cmp);
+        for (int i = cfg->max_features; i < n; i++) sel_score[s[i].cell] = 0.0f;
+        free(s);
+    }
+    /* orientation + descriptor on the level-0 image only (Q10), selected cells only */
+    oracle_compute_fast_angle(angle, pos, sel_score, lv[0].image, lv[0].image_pitch, cfg->width,
+                              cfg->height, K);
+    for (int k = 0; k < K; k++) {
+        if (sel_score[k] > 0.0f)
+            oracle_calc_orb(angle + k, pos + 2 * k, desc + 32 * (size_t)k, desc32 + k,
+                            lv[0].image, lv[0].image_pitch, cfg->width, cfg->height, 1,
+                            cfg->angle_in_radians);
+        /* else: zero descriptor, zero desc32, zero angle (Q5) -- calloc */
+    }
+    int count = 0;
+    for (int k = 0; k < K; k++)
+        if (sel_score[k] > 0.0f) {
+            if (records) {
+                oracle_keypoint *r = records + count;
+                r->x = pos[2 * k];
+                r->y = pos[2 * k + 1];
+                r->score = score[k];
+                r->level = level[k];
+                r->angle = angle[k];
+                memcpy(r->desc, desc + 32 * (size_t)k, 32);
+            }
+            count++;
+        }
+
+    if (pyr_out)
+        for (int l = 0; l < L; l++)
+            if (pyr_out[l]) memcpy(pyr_out[l], lv[l].image, (size_t)lv[l].width * lv[l].height);
+    if (pos_o) memcpy(pos_o, pos, (size_t)K * 2 * sizeof(float));
+    if (score_o) memcpy(score_o, score, (size_t)K * sizeof(float));
+    if (level_o) memcpy(level_o, level, (size_t)K * sizeof(int32_t));
+    if (angle_o) memcpy(angle_o, angle, (size_t)K * sizeof(float));
+    if (desc_o) memcpy(desc_o, desc, (size_t)K * 32);
+    if (desc32_o) memcpy(desc32_o, desc32, (size_t)K * sizeof(uint32_t));
+
+    for (int l = 0; l < L; l++) {
+        free(lv[l].image);
+        free(lv[l].response);
+    }
+    free(lv);
+    free(lut);
+    free(pos);
+    free(score);
+    free(level);
+    free(angle);
+    free(desc);
+    free(desc32);
+    free(sel_score);
+    return count;
+}

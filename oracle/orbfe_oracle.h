@@ -1,0 +1,97 @@
+/* orbfe_oracle.h -- CPU oracle for the ORB front-end hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call this.
+ * The product library (liborbfe.so) never links, loads or falls back to it.
+ *
+ * PARITY UNPINNED BY THE REFERENCE: dsvua/jetracer-orbslam2 holds no tests, golden
+ * vectors or fixtures for this path and its only implementation
+ * is CUDA (src/cuda/ *.cu), which cannot be compiled in this image (needs nvcc,
+ * helper_cuda.h, librealsense2, Eigen).  This file is therefore a statement-by-statement
+ * CPU restatement of those kernels with the determinisation decisions of SURVEY.md
+ * Appendix A, pinned by the known answers derivable from the source (Appendix B) in
+ * tests/test_kat.py and by committed digests in tests/golden/.
+ */
+#ifndef ORBFE_ORACLE_H
+#define ORBFE_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct oracle_level {
+    int width, height;
+    int image_pitch;    /* bytes */
+    uint8_t *image;
+    int response_pitch; /* elements (floats) */
+    float *response;
+} oracle_level;
+
+typedef struct oracle_config {
+    int width, height;
+    int levels;           /* pyramid levels built */
+    int cell;             /* level-0 NMS cell; reference 32 */
+    float fast_threshold; /* reference 13.0f */
+    int min_arc;          /* reference 12 */
+    int max_features;     /* 0 = every non-empty cell (reference); >0 = top-N */
+    int angle_in_radians; /* 0 = reference quirk Q7 */
+} oracle_config;
+
+/* 52-byte keypoint record */
+typedef struct oracle_keypoint {
+    float x, y;
+    float score;
+    int32_t level;
+    float angle;
+    uint8_t desc[32];
+} oracle_keypoint;
+
+/* ---- one function per reference kernel / host function ---- */
+void oracle_gaussian_blur_3x3(uint8_t *blurred, int blurred_pitch, const uint8_t *image,
+                              int image_pitch, int w, int h);
+void oracle_halfsample(const uint8_t *src, int src_pitch, uint8_t *dst, int dst_pitch,
+                       int dst_w, int dst_h);
+void oracle_pyramid_create_levels(const oracle_level *levels, int n_levels);
+int oracle_fast_is_corner(uint32_t mask, int min_arc);
+void oracle_fast_calculate_lut(uint8_t *lut, int min_arc);
+void oracle_fast_calc_corner_response(int w, int h, int pitch, const uint8_t *img, int hb,
+                                      int vb, const uint8_t *lut, float threshold,
+                                      int resp_pitch_elems, float *resp);
+void oracle_grid_nms(const oracle_level *levels, int n_levels, int cell, float *pos /*x,y*/,
+                     float *score, int32_t *level);
+void oracle_detect(const oracle_level *levels, int n_levels, int cell, const uint8_t *lut,
+                   float threshold, float *pos, float *score, int32_t *level);
+void oracle_compute_fast_angle(float *angle, const float *pos, const float *score,
+                               const uint8_t *img, int pitch, int w, int h, int n);
+void oracle_calc_orb(const float *angle, const float *pos, uint8_t *desc_tmp, uint32_t *desc32,
+                     const uint8_t *img, int pitch, int w, int h, int n, int angle_in_radians);
+int oracle_match_keypoints(const float *pos_prev, const uint32_t *desc_prev, int n_prev,
+                           const float *pos_curr, const uint32_t *desc_curr, int n_curr,
+                           int max_px, int max_ham, int32_t *match_idx /*[n_prev], -1 = none*/);
+/* EXT C.9: brute-force 256-bit; (dist, idx) lexicographic minimum; window < 0 = none */
+void oracle_match256(const uint8_t *descA, const float *posA, int nA, const uint8_t *descB,
+                     const float *posB, int nB, int window, int max_dist, int32_t *idx,
+                     int32_t *dist);
+
+/* ---- whole pipeline on one frame ---- */
+int oracle_num_cells(const oracle_config *cfg);
+size_t oracle_level_dims(const oracle_config *cfg, int level, int *w, int *h);
+/* All outputs optional (NULL to skip).  pyr_out[l] must hold w_l*h_l bytes (tight pitch).
+ * Returns the number of records written (score > 0, after top-N), in cell order. */
+int oracle_extract_frame(const oracle_config *cfg, const uint8_t *gray, int gray_pitch,
+                         uint8_t **pyr_out, float *pos, float *score, int32_t *level,
+                         float *angle, uint8_t *desc, uint32_t *desc32,
+                         oracle_keypoint *records);
+
+/* deterministic-math probes for the known-answer tests */
+float oracle_atan2f(float y, float x);
+void oracle_sincosf(float x, float *s, float *c);
+int oracle_has_arc(uint32_t mask, int arc);
+const int8_t *oracle_pattern(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
