@@ -1,0 +1,232 @@
+/* orbfe.h -- C ABI of the MI355X-native ORB front end (liborbfe.so).
+ *
+ * This is the drop-in boundary for the GPU feature path of dsvua/jetracer-orbslam2: the
+ * free functions declared in the reference's src/cuda/ *.cuh and called by
+ * SlamGpuPipeline::buildStream (src/SlamGpuPipeline/buildStream.cpp:338, :424-460,
+ * :545-556).  Each entry point below names the reference declaration it replaces.
+ *
+ * Conventions (differences from the reference are deliberate and listed in DESIGN.md):
+ *   - extern "C", plain pointers and sizes.  Every `d_` pointer is DEVICE memory owned by
+ *     the caller; the library allocates nothing per call (only orbfe_create allocates).
+ *   - every call is asynchronous on the caller's HIP stream and in-order on it; no call
+ *     synchronises the stream or the device.
+ *   - int status return (ORBFE_OK = 0) instead of the reference's abort-on-error
+ *     (checkCudaErrors / exit(1), src/cuda_common.h:69-77); orbfe_last_error() gives text.
+ *   - no global mutable state: the rBRIEF pattern is a compile-time constant (the
+ *     reference uploads it with loadPattern(), src/cuda/orb.cu:218-225) and the FAST LUT
+ *     is a caller buffer as in the reference.  A context is thread-compatible: one
+ *     context per host thread + stream, as the reference runs one buildStream thread per
+ *     stream (src/SlamGpuPipeline/SlamGpuPipeline.cpp:43-50).
+ *   - there is NO CPU fallback: without a HIP device every call returns ORBFE_ERR_NO_DEVICE
+ *     or ORBFE_ERR_HIP.
+ */
+#ifndef ORBFE_H
+#define ORBFE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBFE_VERSION 1
+
+enum {
+    ORBFE_OK = 0,
+    ORBFE_ERR_INVALID_ARG = 1, /* null pointer, non-positive size, bad pitch ...          */
+    ORBFE_ERR_UNSUPPORTED = 2, /* configuration outside the reference regime + EXT rules  */
+    ORBFE_ERR_HIP = 3,         /* a HIP runtime call failed; see orbfe_last_error()       */
+    ORBFE_ERR_NO_DEVICE = 4,
+    ORBFE_ERR_CAPACITY = 5     /* n_frames > max_batch, output too small ...              */
+};
+
+/* hipStream_t without the HIP headers (hipStream_t is `struct ihipStream_t *`). */
+typedef struct ihipStream_t *orbfe_stream_t;
+
+/* Mirror of the reference's pyramid_t (src/cuda/pyramid.cuh:9-18), passed as pointer +
+ * count instead of a std::vector by value. */
+typedef struct orbfe_pyramid_level {
+    size_t image_width;
+    size_t image_height;
+    size_t image_pitch; /* bytes */
+    unsigned char *image;
+    size_t response_pitch; /* bytes, as in the reference (divided by sizeof(float) inside) */
+    float *response;
+} orbfe_pyramid_level;
+
+/* enum fast_score, src/cuda/fast.cuh:18-23.  Only SUM_OF_ABS_DIFF_ON_ARC is on the live
+ * path (src/SlamGpuPipeline/defines.h:9); the others return ORBFE_ERR_UNSUPPORTED. */
+enum {
+    ORBFE_SUM_OF_ABS_DIFF_ALL = 0,
+    ORBFE_SUM_OF_ABS_DIFF_ON_ARC = 1,
+    ORBFE_MAX_THRESHOLD = 2
+};
+
+/* ================= stage API: one frame, caller-owned buffers, reference semantics ===== */
+
+/* gaussian_blur_3x3, src/cuda/orb.cuh:29-35.  Rows 0, h-2, h-1 are written as 0. */
+int orbfe_gaussian_blur_3x3(unsigned char *d_blurred, int blurred_pitch,
+                            const unsigned char *d_image, int image_pitch, int image_width,
+                            int image_height, orbfe_stream_t stream);
+
+/* pyramid_create_levels, src/cuda/pyramid.cuh:20-21: level i (i >= 1) = 2x2 box average of
+ * level i-1.  levels[i].image_width/height must equal floor(previous / 2). */
+int orbfe_pyramid_create_levels(const orbfe_pyramid_level *levels, int n_levels,
+                                orbfe_stream_t stream);
+
+/* fast_gpu_calculate_lut, src/cuda/fast.cuh:25-26: 65536-byte table, lut[m] = 1 iff the
+ * 16-bit ring mask m holds a cyclic run of >= min_arc ones.  Unlike the reference (legacy
+ * default stream, fast.cu:299) it runs on `stream`. */
+int orbfe_fast_calculate_lut(unsigned char *d_corner_lut, int min_arc_length,
+                             orbfe_stream_t stream);
+
+/* fast_gpu_calc_corner_response, src/cuda/fast.cuh:28-40. */
+int orbfe_fast_calc_corner_response(int image_width, int image_height, int image_pitch,
+                                    const unsigned char *d_image, int horizontal_border,
+                                    int vertical_border, const unsigned char *d_corner_lut,
+                                    float threshold, int min_arc_length, int score,
+                                    int response_pitch_elements, float *d_response,
+                                    orbfe_stream_t stream);
+
+/* grid_nms, src/cuda/nms.cuh:11-15: one keypoint per 32x32 level-0 cell over all levels.
+ * d_pos is float2[K], d_score float[K], d_level int[K], K = ceil(W/32)*ceil(H/32).
+ * Empty cells get score 0, pos (0,0), level 0. */
+int orbfe_grid_nms(const orbfe_pyramid_level *levels, int n_levels, float *d_pos,
+                   float *d_score, int *d_level, orbfe_stream_t stream);
+
+/* detect, src/cuda/fast.cuh:42-48 = corner response on every level, then grid_nms. */
+int orbfe_detect(const orbfe_pyramid_level *levels, int n_levels,
+                 const unsigned char *d_corner_lut, float threshold, float *d_pos,
+                 float *d_score, int *d_level, orbfe_stream_t stream);
+
+/* compute_fast_angle, src/cuda/orb.cuh:9-16.  Intensity-centroid angle in radians for all
+ * keypoints_num entries of d_keypoints_pos (float2[]). */
+int orbfe_compute_fast_angle(float *d_keypoints_angle, const float *d_keypoints_pos,
+                             const unsigned char *d_image, int image_pitch, int image_width,
+                             int image_height, int keypoints_num, orbfe_stream_t stream);
+
+/* calc_orb, src/cuda/orb.cuh:18-27: 32-byte rBRIEF into d_descriptors_tmp[K][32] and the
+ * reference's 32-bit "compressed" word (bit i = byte i == 1) into d_descriptors[K]. */
+int orbfe_calc_orb(const float *d_keypoints_angle, const float *d_keypoints_pos,
+                   unsigned char *d_descriptors_tmp, uint32_t *d_descriptors,
+                   const unsigned char *d_image, int image_pitch, int image_width,
+                   int image_height, int keypoints_num, orbfe_stream_t stream);
+
+/* loadPattern, src/cuda/orb.cuh:37.  The pattern is compiled in; kept so that a caller's
+ * init sequence (SlamGpuPipeline.cpp:52) ports line for line.  Always ORBFE_OK. */
+int orbfe_load_pattern(void);
+
+/* match_keypoints, src/cuda/post_processing.cuh:40-51, without the RGB-D parts: the caller
+ * passes the (re-projected) prev positions directly.  For every prev keypoint i the best
+ * curr keypoint within +-max_pixel_distance in x and y and Hamming distance
+ * < max_hamming_distance on the 32-bit words; d_match_idx[i] = curr index or -1;
+ * *d_num_matched = number of matches.  The reference's visiting order (tiles of 32,
+ * rotated by i % 32, partial-tile skip) is reproduced. */
+int orbfe_match_keypoints(const float *d_pos_prev, const uint32_t *d_descriptors_prev,
+                          int keypoints_num_prev, const float *d_pos_curr,
+                          const uint32_t *d_descriptors_curr, int keypoints_num_curr,
+                          int max_pixel_distance, int max_hamming_distance,
+                          int32_t *d_match_idx, int32_t *d_num_matched,
+                          orbfe_stream_t stream);
+
+/* EXT: brute-force 256-bit Hamming matcher.  For every descriptor i of A the
+ * lexicographic minimum (distance, index) over B; window < 0 disables the position gate
+ * (then d_posA/d_posB may be NULL); matches with distance > max_distance give -1/-1. */
+int orbfe_match256(const unsigned char *d_descA, const float *d_posA, int nA,
+                   const unsigned char *d_descB, const float *d_posB, int nB, int window,
+                   int max_distance, int32_t *d_idx, int32_t *d_dist, orbfe_stream_t stream);
+
+/* ================= batch API: many frames per call, context-owned scratch ============== */
+
+typedef struct orbfe_config {
+    int32_t width, height;     /* level-0 frame size                                       */
+    int32_t levels;            /* pyramid levels built, 1..16                              */
+    int32_t cell;              /* level-0 NMS cell: 8, 16, 32 (reference) or 64            */
+    int32_t fast_threshold;    /* FAST epsilon, 1..254 (reference 13, defines.h:7)         */
+    int32_t min_arc;           /* 9..12 (reference 12, defines.h:8)                        */
+    int32_t max_features;      /* 0 = every non-empty cell (reference); N = top-N by       */
+                               /* (score desc, cell asc)                                   */
+    int32_t angle_in_radians;  /* 0 = reference (radians used as degrees); 1 = fixed       */
+    int32_t max_batch;         /* frames per orbfe_extract call the context is sized for   */
+    int32_t device;            /* HIP device ordinal                                       */
+} orbfe_config;
+
+/* 52-byte keypoint record, little endian. */
+typedef struct orbfe_keypoint {
+    float x, y;      /* level-0 pixel coordinates                                 */
+    float score;     /* FAST sum-of-abs-diff-on-arc score (an integer)            */
+    int32_t level;   /* pyramid level that won the cell                           */
+    float angle;     /* radians, as stored by compute_fast_angle                  */
+    uint8_t desc[32];
+} orbfe_keypoint;
+
+/* Optional cell-indexed struct-of-arrays view, the layout the reference keeps
+ * (src/SlamGpuPipeline/buildStream.cpp:289-296, :255-258).  Each non-NULL pointer is
+ * device memory for n_frames * K elements (pos: 2 floats, desc: 32 bytes per cell). */
+typedef struct orbfe_soa {
+    float *d_pos;
+    float *d_score;
+    int32_t *d_level;
+    float *d_angle;
+    uint8_t *d_desc;
+    uint32_t *d_desc32;
+} orbfe_soa;
+
+typedef struct orbfe_ctx orbfe_ctx;
+
+void orbfe_default_config(orbfe_config *cfg, int width, int height);
+int orbfe_create(const orbfe_config *cfg, orbfe_ctx **out);
+void orbfe_destroy(orbfe_ctx *ctx);
+/* Text of the last error on this context (ctx == NULL: last error of orbfe_create or of a
+ * stage call on the calling thread). */
+const char *orbfe_last_error(const orbfe_ctx *ctx);
+
+int orbfe_num_cells(const orbfe_ctx *ctx);     /* K                                        */
+int orbfe_max_keypoints(const orbfe_ctx *ctx); /* records per frame: min(K, max_features)  */
+int orbfe_num_levels(const orbfe_ctx *ctx);
+/* Geometry and device address of pyramid level `level` of frame 0 inside the context;
+ * frame f lives *frame_stride bytes further per frame. */
+int orbfe_level_info(const orbfe_ctx *ctx, int level, int *width, int *height, size_t *pitch,
+                     const uint8_t **d_image, size_t *frame_stride);
+
+/* a2+a3: blur + pyramid for n_frames frames. d_gray: frame f at d_gray + f*frame_stride. */
+int orbfe_build_pyramid(orbfe_ctx *ctx, const uint8_t *d_gray, size_t pitch,
+                        size_t frame_stride, int n_frames, orbfe_stream_t stream);
+
+/* a4..a7 on the context's pyramid: fused FAST score + 3x3 NMS + per-cell maximum over all
+ * detection levels (levels with cell >> level >= 1) of n_frames frames. */
+int orbfe_detect_batch(orbfe_ctx *ctx, int n_frames, orbfe_stream_t stream);
+
+/* selection (all non-empty cells or top-N) + a8 orientation + a9/a10 descriptors for the
+ * frames last detected; outputs as orbfe_extract. */
+int orbfe_describe_batch(orbfe_ctx *ctx, int n_frames, orbfe_keypoint *d_records,
+                         int32_t *d_counts, const orbfe_soa *soa, orbfe_stream_t stream);
+
+/* Whole extraction (a2..a10) for n_frames frames: pyramid, fused FAST + grid NMS,
+ * selection, orientation, descriptors.  d_records holds n_frames * orbfe_max_keypoints()
+ * records (frame f starts at f * max_keypoints), in cell order; d_counts[f] = number of
+ * valid records of frame f.  soa may be NULL. */
+int orbfe_extract(orbfe_ctx *ctx, const uint8_t *d_gray, size_t pitch, size_t frame_stride,
+                  int n_frames, orbfe_keypoint *d_records, int32_t *d_counts,
+                  const orbfe_soa *soa, orbfe_stream_t stream);
+
+/* a11 over a batch: for f = 1 .. n_frames-1 match the records of frame f-1 (prev) against
+ * frame f (curr).  mode 0 = reference semantics (32-bit word, +-window px, distance <
+ * max_distance); mode 1 = EXT 256-bit brute force (window < 0: none; distance <=
+ * max_distance).  d_idx / d_dist: (n_frames-1) * max_keypoints int32 (d_dist may be NULL). */
+int orbfe_match_batch(orbfe_ctx *ctx, const orbfe_keypoint *d_records, const int32_t *d_counts,
+                      int n_frames, int mode, int window, int max_distance, int32_t *d_idx,
+                      int32_t *d_dist, orbfe_stream_t stream);
+
+/* ================= harness helpers (tests, bench) ===================================== */
+int orbfe_device_count(void);
+int orbfe_memcpy_d2h(void *dst, const void *d_src, size_t bytes, orbfe_stream_t stream);
+int orbfe_memcpy_h2d(void *d_dst, const void *src, size_t bytes, orbfe_stream_t stream);
+int orbfe_stream_sync(orbfe_stream_t stream);
+int orbfe_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBFE_H */

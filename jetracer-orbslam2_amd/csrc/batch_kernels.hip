@@ -1,0 +1,695 @@
+// batch_kernels.hip -- the throughput path: many frames per call, context-owned pyramid.
+// gfx950 only.  Pipeline per orbfe_extract call (all on the caller's stream):
+//   memset cell keys -> blur (level 0) -> halving (levels 1..L-1) -> fused FAST + grid NMS
+//   -> per-frame selection / compaction -> orientation + rBRIEF -> 52-byte records.
+// The f32 response maps of the reference (src/cuda/fast.cu, nms.cu) never exist in HBM:
+// scores live in LDS as u16 and the per-cell winner is an atomicMax of nms_key().
+#include "orbfe_internal.hpp"
+#include "device_common.hpp"
+
+#include <vector>
+
+namespace orbfe {
+
+// ------------------------------------------------------------------------------------
+// a2 batch  blur: one thread = 4 adjacent outputs (one dword store).  Seams every 32 columns
+// (Q2) fall on dword-group boundaries, so only the first/last pixel of a group can see one.
+// VEC = source rows can be read as aligned dwords.
+// ------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+blur_batch_kernel(uint8_t *__restrict__ dst, int dst_pitch, size_t dst_fstride,
+                  const uint8_t *__restrict__ src, int src_pitch, size_t src_fstride, int w, int h)
+{
+    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x0 >= w || y >= h) return;
+    dst += (size_t)blockIdx.z * dst_fstride;
+    src += (size_t)blockIdx.z * src_fstride;
+    uint32_t *o = reinterpret_cast<uint32_t *>(dst + (size_t)y * dst_pitch + x0);
+    if (y == 0 || y >= h - 2) {
+        *o = 0u;
+        return;
+    }
+    int col[3][6]; // rows y-1, y, y+1; columns x0-1 .. x0+4
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const uint8_t *row = src + (size_t)(y - 1 + r) * src_pitch;
+        if (VEC && x0 + 3 < w) {
+            const uint32_t v = *reinterpret_cast<const uint32_t *>(row + x0);
+            col[r][1] = v & 255u;
+            col[r][2] = (v >> 8) & 255u;
+            col[r][3] = (v >> 16) & 255u;
+            col[r][4] = v >> 24;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) col[r][1 + i] = (x0 + i < w) ? row[x0 + i] : 0;
+        }
+        col[r][0] = ((x0 & 31) == 0) ? col[r][1] : (int)row[x0 - 1];
+        // right neighbour of pixel x0+3; a seam or the image edge substitutes the pixel itself
+        col[r][5] = (((x0 + 3) & 31) == 31 || x0 + 3 >= w - 1) ? col[r][4] : (int)row[x0 + 4];
+    }
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        // x == w-1 inside the group: its right neighbour is itself
+        const bool last = (x0 + i == w - 1);
+        const int a_r = last ? col[0][1 + i] : col[0][2 + i];
+        const int b_r = last ? col[1][1 + i] : col[1][2 + i];
+        const int c_r = last ? col[2][1 + i] : col[2][2 + i];
+        const int s = 2 * col[0][1 + i] + 4 * col[1][1 + i] + 2 * col[2][1 + i] + col[0][i] + a_r +
+                      2 * col[1][i] + 2 * b_r + col[2][i] + c_r;
+        out |= (uint32_t)((s + 8) >> 4) << (8 * i);
+    }
+    *o = out; // columns >= w of the last group land in the row padding (pitch is 64-aligned)
+}
+
+// a3 batch  halving: one thread = 4 outputs from two aligned 8-byte reads.
+__global__ void __launch_bounds__(256)
+halfsample_batch_kernel(uint8_t *__restrict__ pyr, size_t fstride, size_t src_off, int src_pitch,
+                        size_t dst_off, int dst_pitch, int dw, int dh)
+{
+    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x0 >= dw || y >= dh) return;
+    uint8_t *base = pyr + (size_t)blockIdx.z * fstride;
+    const uint8_t *t = base + src_off + (size_t)(2 * y) * src_pitch + 2 * x0;
+    const uint2 a = *reinterpret_cast<const uint2 *>(t);
+    const uint2 b = *reinterpret_cast<const uint2 *>(t + src_pitch);
+    // horizontal pair sums of bytes, two 16-bit lanes per dword
+    const uint32_t m = 0x00FF00FFu;
+    const uint32_t s0 = (a.x & m) + ((a.x >> 8) & m) + (b.x & m) + ((b.x >> 8) & m);
+    const uint32_t s1 = (a.y & m) + ((a.y >> 8) & m) + (b.y & m) + ((b.y >> 8) & m);
+    const uint32_t out = ((s0 >> 2) & 255u) | (((s0 >> 18) & 255u) << 8) |
+                         (((s1 >> 2) & 255u) << 16) | (((s1 >> 18) & 255u) << 24);
+    *reinterpret_cast<uint32_t *>(base + dst_off + (size_t)y * dst_pitch + x0) = out;
+}
+
+// ------------------------------------------------------------------------------------
+// a5 + a6 fused  FAST score + 3x3 NMS + per-cell maximum for one 64x32 tile of one level
+// of one frame.  LDS: pixel tile with a 4-pixel halo (ring radius 3 + NMS radius 1), u16
+// score tile with a 1-pixel halo, one key per cell that intersects the tile.
+// ------------------------------------------------------------------------------------
+constexpr int kPxW = kTileW + 8, kPxH = kTileH + 8; // 72 x 40
+constexpr int kScW = kTileW + 2, kScH = kTileH + 2; // 66 x 34
+constexpr int kScPitch = kScW + 2;                   // 68
+
+__global__ void __launch_bounds__(256)
+detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr,
+                   const TileDesc *__restrict__ tiles, uint32_t *__restrict__ cellkey)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_px[kPxH][kPxW];
+    __shared__ uint16_t s_sc[kScH][kScPitch];
+    __shared__ uint32_t s_key[kTileW * kTileH];
+
+    const TileDesc td = tiles[blockIdx.x];
+    const int f = blockIdx.y;
+    const int l = td.level;
+    const int W = g.lv[l].w, H = g.lv[l].h, P = g.lv[l].pitch;
+    const uint8_t *img = pyr + (size_t)f * g.frame_stride + g.lv[l].offset;
+    const int x0 = td.tx * kTileW, y0 = td.ty * kTileH;
+    const int tid = threadIdx.x;
+
+    // pixel tile, as dwords (x0 - 4 is dword aligned; rows are 64-byte aligned)
+    for (int i = tid; i < kPxH * (kPxW / 4); i += 256) {
+        const int r = i / (kPxW / 4), q = i % (kPxW / 4);
+        const int gy = y0 - 4 + r, gx = x0 - 4 + 4 * q;
+        uint32_t v = 0;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < P)
+            v = *reinterpret_cast<const uint32_t *>(img + (size_t)gy * P + gx);
+        reinterpret_cast<uint32_t *>(&s_px[r][0])[q] = v;
+    }
+    const int c = g.cell >> l;
+    const int ncx = kTileW / c > 0 ? kTileW / c : 1, ncy = kTileH / c > 0 ? kTileH / c : 1;
+    for (int i = tid; i < ncx * ncy; i += 256) s_key[i] = 0u;
+    __syncthreads();
+
+    // scores for the tile and its 1-pixel halo
+    for (int i = tid; i < kScH * kScW; i += 256) {
+        const int ry = i / kScW - 1, rx = i % kScW - 1;
+        const int x = x0 + rx, y = y0 + ry;
+        int sc = 0;
+        if (x >= 3 && y >= 3 && x < W - 3 && y < H - 3)
+            sc = fast_score_int(&s_px[ry + 4][rx + 4], kPxW, g.threshold, g.arc);
+        s_sc[ry + 1][rx + 1] = (uint16_t)sc;
+    }
+    __syncthreads();
+
+    // strict 3x3 maximum, then the cell's maximum key
+    for (int i = tid; i < kTileW * kTileH; i += 256) {
+        const int ry = i / kTileW, rx = i % kTileW;
+        const uint16_t *q = &s_sc[ry + 1][rx + 1];
+        const int v = q[0];
+        if (v == 0) continue;
+        const bool is_max = v > q[-kScPitch] && v > q[-kScPitch + 1] && v > q[1] &&
+                            v > q[kScPitch + 1] && v > q[kScPitch] && v > q[kScPitch - 1] &&
+                            v > q[-1] && v > q[-kScPitch - 1];
+        if (!is_max) continue;
+        const uint32_t key = nms_key(v, l, x0 + rx, y0 + ry, g.cell);
+        atomicMax(&s_key[(ry / c) * ncx + (rx / c)], key);
+    }
+    __syncthreads();
+
+    for (int i = tid; i < ncx * ncy; i += 256) {
+        const uint32_t key = s_key[i];
+        if (key == 0u) continue;
+        const int cx = x0 / c + i % ncx, cy = y0 / c + i / ncx;
+        if (cx < g.cells_x && cy < g.cells_y)
+            atomicMax(&cellkey[(size_t)f * g.K + cy * g.cells_x + cx], key);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Selection + compaction, one workgroup per frame.  Reference mode keeps every non-empty
+// cell; max_features = N keeps the N best by (score desc, cell asc) (EXT ii).  Output is in
+// cell order either way, so it is deterministic.  Also fills the optional SoA view.
+// ------------------------------------------------------------------------------------
+__device__ inline int block_excl_scan(bool flag, int *s_wave, int *total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint64_t m = __ballot(flag);
+    const int pre = (int)__popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads();
+    if (lane == 0) s_wave[wv] = (int)__popcll(m);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int v = s_wave[u];
+        off += (u < wv) ? v : 0;
+        tot += v;
+    }
+    *total = tot;
+    return off + pre;
+}
+
+__global__ void __launch_bounds__(256)
+select_kernel(DeviceGeom g, const uint32_t *__restrict__ cellkey, int32_t *__restrict__ sel,
+              int32_t *__restrict__ selcount, int32_t *__restrict__ counts_out, orbfe_soa soa)
+{
+    __shared__ uint32_t s_hist[4096];
+    __shared__ int s_wave[4];
+    __shared__ int s_tot[256];
+    __shared__ int s_thr, s_quota;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const uint32_t *keys = cellkey + (size_t)f * g.K;
+
+    if (tid == 0) {
+        s_thr = 0;          // keep score > s_thr ...
+        s_quota = 0;        // ... plus the first s_quota cells with score == s_thr
+    }
+    if (g.max_features > 0) {
+        for (int i = tid; i < 4096; i += 256) s_hist[i] = 0u;
+        __syncthreads();
+        for (int k = tid; k < g.K; k += 256) {
+            const uint32_t s = keys[k] >> 15;
+            if (s) atomicAdd(&s_hist[s], 1u);
+        }
+        __syncthreads();
+        // thread t owns bins 16t .. 16t+15; `above` = how many scores lie in higher bins
+        int mine = 0;
+        for (int b = 0; b < 16; b++) mine += (int)s_hist[16 * tid + b];
+        s_tot[tid] = mine;
+        __syncthreads();
+        int above = 0;
+        for (int u = tid + 1; u < 256; u++) above += s_tot[u];
+        for (int b = 15; b >= 0; b--) {
+            const int n = (int)s_hist[16 * tid + b];
+            if (above < g.max_features && above + n >= g.max_features && n > 0) {
+                s_thr = 16 * tid + b;
+                s_quota = g.max_features - above;
+            }
+            above += n;
+        }
+    }
+    __syncthreads();
+    const int thr = s_thr, quota = s_quota;
+
+    int n_sel = 0, n_tie = 0;
+    for (int base = 0; base < g.K; base += 256) {
+        const int k = base + tid;
+        const bool in = k < g.K;
+        const uint32_t key = in ? keys[k] : 0u;
+        const int score = (int)(key >> 15);
+        const bool tie = in && thr > 0 && score == thr;
+        int tie_tot;
+        const int tie_rank = block_excl_scan(tie, s_wave, &tie_tot);
+        const bool keep = in && score > 0 && (score > thr || (tie && n_tie + tie_rank < quota));
+        int keep_tot;
+        const int slot = block_excl_scan(keep, s_wave, &keep_tot);
+        if (keep) sel[(size_t)f * g.cap + n_sel + slot] = k;
+        if (in && (soa.d_pos || soa.d_score || soa.d_level || soa.d_angle || soa.d_desc ||
+                   soa.d_desc32)) {
+            int s, l, x, y;
+            nms_decode(key, k % g.cells_x, k / g.cells_x, g.cell, &s, &l, &x, &y);
+            const size_t o = (size_t)f * g.K + k;
+            if (soa.d_pos) {
+                soa.d_pos[2 * o] = (float)x;
+                soa.d_pos[2 * o + 1] = (float)y;
+            }
+            if (soa.d_score) soa.d_score[o] = (float)s;
+            if (soa.d_level) soa.d_level[o] = l;
+            if (!keep) { // unselected / empty cells: zero angle and descriptor (Q5)
+                if (soa.d_angle) soa.d_angle[o] = 0.0f;
+                if (soa.d_desc32) soa.d_desc32[o] = 0u;
+                if (soa.d_desc) {
+                    uint32_t *d = reinterpret_cast<uint32_t *>(soa.d_desc + 32 * o);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) d[j] = 0u;
+                }
+            }
+        }
+        n_sel += keep_tot;
+        n_tie += tie_tot;
+    }
+    if (tid == 0) {
+        selcount[f] = n_sel;
+        if (counts_out) counts_out[f] = n_sel;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// a8 + a9 + a10 fused: one wave per selected keypoint -> one 52-byte record (+ SoA view).
+// Orientation and descriptor sample the level-0 image only (Q10).
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32_t *__restrict__ cellkey,
+                const int32_t *__restrict__ sel, const int32_t *__restrict__ selcount,
+                orbfe_keypoint *__restrict__ records, orbfe_soa soa)
+{
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int f = blockIdx.y;
+    if (slot >= selcount[f]) return; // whole wave
+    const int cell = sel[(size_t)f * g.cap + slot];
+    const uint32_t key = cellkey[(size_t)f * g.K + cell];
+    int score, level, x, y;
+    nms_decode(key, cell % g.cells_x, cell / g.cells_x, g.cell, &score, &level, &x, &y);
+    const uint8_t *img = pyr + (size_t)f * g.frame_stride + g.lv[0].offset;
+    const int P = g.lv[0].pitch;
+
+    int m10, m01;
+    patch_moments(img, P, g.W, g.H, x, y, lane, &m10, &m01);
+    const float angle = orbfe_atan2f((float)m01, (float)m10);
+
+    uint64_t d[4] = {0, 0, 0, 0};
+    if (!orb_border_zero(x, y, g.W, g.H, g.angle_in_radians))
+        orb_describe(img, P, x, y, angle, g.angle_in_radians, lane, d);
+
+    uint32_t *rec = reinterpret_cast<uint32_t *>(records + (size_t)f * g.cap + slot);
+    if (lane < 8) rec[5 + lane] = (uint32_t)(d[lane >> 1] >> (32 * (lane & 1)));
+    if (lane == 8) rec[0] = __float_as_uint((float)x);
+    if (lane == 9) rec[1] = __float_as_uint((float)y);
+    if (lane == 10) rec[2] = __float_as_uint((float)score);
+    if (lane == 11) rec[3] = (uint32_t)level;
+    if (lane == 12) rec[4] = __float_as_uint(angle);
+
+    const size_t o = (size_t)f * g.K + cell;
+    if (soa.d_angle && lane == 13) soa.d_angle[o] = angle;
+    if (soa.d_desc32 && lane == 14) soa.d_desc32[o] = orb_compress(d);
+    if (soa.d_desc && lane < 8)
+        reinterpret_cast<uint32_t *>(soa.d_desc + 32 * o)[lane] =
+            (uint32_t)(d[lane >> 1] >> (32 * (lane & 1)));
+}
+
+// ------------------------------------------------------------------------------------
+// a11 over a batch: records of frame p (prev) against frame p + 1 (curr).
+// ------------------------------------------------------------------------------------
+__device__ inline uint32_t compress_words(const uint32_t w[8])
+{
+    uint32_t out = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) out |= (uint32_t)(((w[j] >> (8 * k)) & 255u) == 1u) << (4 * j + k);
+    return out;
+}
+
+__global__ void __launch_bounds__(256)
+match_batch_ref_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *__restrict__ counts,
+                       int cap, float win, int max_ham, int32_t *__restrict__ out_idx,
+                       int32_t *__restrict__ out_dist)
+{
+    __shared__ float s_x[32], s_y[32];
+    __shared__ uint32_t s_d[32];
+    const int p = blockIdx.y;
+    const int nA = counts[p], nB = counts[p + 1];
+    const uint32_t *A = reinterpret_cast<const uint32_t *>(records + (size_t)p * cap);
+    const uint32_t *B = reinterpret_cast<const uint32_t *>(records + (size_t)(p + 1) * cap);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int tid = i & 31;
+    const bool live = i < nA;
+    float px = 0.f, py = 0.f;
+    uint32_t d = 0;
+    if (live) {
+        const uint32_t *r = A + 13 * (size_t)i;
+        px = __uint_as_float(r[0]);
+        py = __uint_as_float(r[1]);
+        uint32_t w[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) w[j] = r[5 + j];
+        d = compress_words(w);
+    }
+    int best = 9999999, pair = -1;
+    for (int base = 0; base < nB; base += 32) {
+        __syncthreads();
+        if (threadIdx.x < 32 && base + (int)threadIdx.x < nB) {
+            const uint32_t *r = B + 13 * (size_t)(base + threadIdx.x);
+            s_x[threadIdx.x] = __uint_as_float(r[0]);
+            s_y[threadIdx.x] = __uint_as_float(r[1]);
+            uint32_t w[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) w[j] = r[5 + j];
+            s_d[threadIdx.x] = compress_words(w);
+        }
+        __syncthreads();
+        const int m = (base + 32 >= nB) ? nB - base : 32;
+        if (live && tid < m) {
+            int j = tid;
+            for (int s = 0; s < m; s++) {
+                if (fabsf(px - s_x[j]) <= win && fabsf(py - s_y[j]) <= win) {
+                    const int hd = __popc(d ^ s_d[j]);
+                    if (hd < max_ham && hd < best) {
+                        best = hd;
+                        pair = base + j;
+                    }
+                }
+                j = (j + 1 == m) ? 0 : j + 1;
+            }
+        }
+    }
+    if (i < cap) {
+        out_idx[(size_t)p * cap + i] = live ? pair : -1;
+        if (out_dist) out_dist[(size_t)p * cap + i] = (live && pair >= 0) ? best : -1;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+match_batch_256_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *__restrict__ counts,
+                       int cap, int window, int max_dist, int32_t *__restrict__ out_idx,
+                       int32_t *__restrict__ out_dist)
+{
+    constexpr int T = 256;
+    __shared__ uint4 s_b[T * 2];
+    __shared__ float2 s_p[T];
+    const int p = blockIdx.y;
+    const int nA = counts[p], nB = counts[p + 1];
+    const uint32_t *A = reinterpret_cast<const uint32_t *>(records + (size_t)p * cap);
+    const uint32_t *B = reinterpret_cast<const uint32_t *>(records + (size_t)(p + 1) * cap);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < nA;
+    uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float ax = 0.f, ay = 0.f;
+    if (live) {
+        const uint32_t *r = A + 13 * (size_t)i;
+        ax = __uint_as_float(r[0]);
+        ay = __uint_as_float(r[1]);
+#pragma unroll
+        for (int j = 0; j < 8; j++) a[j] = r[5 + j];
+    }
+    const float win = (float)window;
+    int best = 1 << 30, best_j = -1;
+    for (int base = 0; base < nB; base += T) {
+        const int m = min(T, nB - base);
+        __syncthreads();
+        uint32_t *sb = reinterpret_cast<uint32_t *>(s_b);
+        for (int t = threadIdx.x; t < 8 * m; t += 256) sb[t] = B[13 * (size_t)(base + (t >> 3)) + 5 + (t & 7)];
+        for (int t = threadIdx.x; t < m; t += 256)
+            s_p[t] = make_float2(__uint_as_float(B[13 * (size_t)(base + t)]),
+                                 __uint_as_float(B[13 * (size_t)(base + t) + 1]));
+        __syncthreads();
+        for (int j = 0; j < m; j++) {
+            const uint4 b0 = s_b[2 * j], b1 = s_b[2 * j + 1];
+            int dist = __popc(a[0] ^ b0.x) + __popc(a[1] ^ b0.y) + __popc(a[2] ^ b0.z) +
+                       __popc(a[3] ^ b0.w) + __popc(a[4] ^ b1.x) + __popc(a[5] ^ b1.y) +
+                       __popc(a[6] ^ b1.z) + __popc(a[7] ^ b1.w);
+            if (window >= 0) {
+                const float2 pb = s_p[j];
+                if (fabsf(ax - pb.x) > win || fabsf(ay - pb.y) > win) dist = 1 << 30;
+            }
+            if (dist < best) {
+                best = dist;
+                best_j = base + j;
+            }
+        }
+    }
+    if (i < cap) {
+        const bool ok = live && best_j >= 0 && best <= max_dist;
+        out_idx[(size_t)p * cap + i] = ok ? best_j : -1;
+        if (out_dist) out_dist[(size_t)p * cap + i] = ok ? best : -1;
+    }
+}
+
+} // namespace orbfe
+
+// ======================================================================================
+// C ABI
+// ======================================================================================
+using namespace orbfe;
+
+static inline hipStream_t S(orbfe_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+#define CTX_FAIL(ctx, code, ...)                                                            \
+    do {                                                                                    \
+        format_error((ctx) ? (ctx)->err : nullptr, __VA_ARGS__);                            \
+        return code;                                                                        \
+    } while (0)
+
+#define CTX_LAUNCH_CHECK(ctx, what)                                                         \
+    do {                                                                                    \
+        hipError_t e_ = hipGetLastError();                                                  \
+        if (e_ != hipSuccess) CTX_FAIL(ctx, ORBFE_ERR_HIP, "%s launch failed: %s", what,    \
+                                       hipGetErrorString(e_));                              \
+    } while (0)
+
+extern "C" {
+
+void orbfe_default_config(orbfe_config *cfg, int width, int height)
+{
+    if (!cfg) return;
+    cfg->width = width;
+    cfg->height = height;
+    cfg->levels = 1;          // PYRAMID_LEVELS, src/SlamGpuPipeline/defines.h:2
+    cfg->cell = 32;           // CELL_SIZE_WIDTH/HEIGHT, defines.h:17-18; nms.cu:266-267
+    cfg->fast_threshold = 13; // FAST_EPSILON, defines.h:7
+    cfg->min_arc = 12;        // FAST_MIN_ARC_LENGTH, defines.h:8
+    cfg->max_features = 0;
+    cfg->angle_in_radians = 0;
+    cfg->max_batch = 1;
+    cfg->device = 0;
+}
+
+const char *orbfe_last_error(const orbfe_ctx *ctx) { return ctx ? ctx->err : thread_error(); }
+
+int orbfe_create(const orbfe_config *cfg, orbfe_ctx **out)
+{
+    if (!cfg || !out) CTX_FAIL((orbfe_ctx *)nullptr, ORBFE_ERR_INVALID_ARG, "orbfe_create: null argument");
+    *out = nullptr;
+    if (cfg->width < 8 || cfg->height < 8 || cfg->width > 16384 || cfg->height > 16384)
+        CTX_FAIL((orbfe_ctx *)nullptr, ORBFE_ERR_INVALID_ARG, "orbfe_create: frame size %dx%d out of range", cfg->width, cfg->height);
+    if (cfg->levels < 1 || cfg->levels > kMaxLevels)
+        CTX_FAIL((orbfe_ctx *)nullptr, ORBFE_ERR_INVALID_ARG, "orbfe_create: levels %d not in 1..%d", cfg->levels, kMaxLevels);
+    if (cfg->cell != 8 && cfg->cell != 16 && cfg->cell != 32 && cfg->cell != 64)
+        CTX_FAIL((orbfe_ctx *)nullptr, ORBFE_ERR_UNSUPPORTED, "orbfe_create: cell %d not in {8,16,32,64}", cfg->cell);
+    if (cfg->min_arc < 9 || cfg->min_arc > 12) // guard upstream vilib had (fast_gpu.cpp:77), Q12
+        CTX_FAIL((orbfe_ctx *)nullptr, ORBFE_ERR_UNSUPPORTED, "orbfe_create: min_arc %d not in 9..12", cfg->min_arc);
+    if (cfg->fast_threshold < 1 || cfg->fast_threshold > 254)
+        CTX_FAIL((orbfe_ctx *)nullptr, ORBFE_ERR_INVALID_ARG, "orbfe_create: fast_threshold %d not in 1..254", cfg->fast_threshold);
+    if (cfg->max_features < 0 || cfg->max_batch < 1)
+        CTX_FAIL((orbfe_ctx *)nullptr, ORBFE_ERR_INVALID_ARG, "orbfe_create: max_features/max_batch");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        CTX_FAIL((orbfe_ctx *)nullptr, ORBFE_ERR_NO_DEVICE, "orbfe_create: no HIP device (this library has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev)
+        CTX_FAIL((orbfe_ctx *)nullptr, ORBFE_ERR_INVALID_ARG, "orbfe_create: device %d of %d", cfg->device, ndev);
+    ORBFE_HIP_TRY(nullptr, hipSetDevice(cfg->device));
+
+    orbfe_ctx *ctx = new orbfe_ctx();
+    ctx->cfg = *cfg;
+    DeviceGeom &g = ctx->g;
+    memset(&g, 0, sizeof(g));
+    g.W = cfg->width;
+    g.H = cfg->height;
+    g.L = cfg->levels;
+    g.cell = cfg->cell;
+    g.cells_x = (g.W + g.cell - 1) / g.cell;
+    g.cells_y = (g.H + g.cell - 1) / g.cell;
+    g.K = g.cells_x * g.cells_y;
+    g.cap = (cfg->max_features > 0 && cfg->max_features < g.K) ? cfg->max_features : g.K;
+    g.threshold = cfg->fast_threshold;
+    g.arc = cfg->min_arc;
+    g.max_features = cfg->max_features;
+    g.angle_in_radians = cfg->angle_in_radians ? 1 : 0;
+    size_t off = 0;
+    for (int l = 0; l < g.L; l++) {
+        g.lv[l].w = g.W >> l;
+        g.lv[l].h = g.H >> l;
+        g.lv[l].pitch = (int)align_up((size_t)(g.lv[l].w > 0 ? g.lv[l].w : 1), 64);
+        g.lv[l].offset = off;
+        off += align_up((size_t)g.lv[l].pitch * (size_t)(g.lv[l].h > 0 ? g.lv[l].h : 1), 256);
+    }
+    g.frame_stride = off;
+    g.Ld = 0;
+    while (g.Ld < g.L && (g.cell >> g.Ld) > 0 && g.lv[g.Ld].w > 0 && g.lv[g.Ld].h > 0) g.Ld++;
+
+    std::vector<TileDesc> tiles;
+    for (int l = 0; l < g.Ld; l++) {
+        if (g.lv[l].w < 7 || g.lv[l].h < 7) continue; // no pixel is >= 3 from every border
+        const int tx = (g.lv[l].w + kTileW - 1) / kTileW, ty = (g.lv[l].h + kTileH - 1) / kTileH;
+        for (int y = 0; y < ty; y++)
+            for (int x = 0; x < tx; x++) tiles.push_back(TileDesc{(int16_t)l, (int16_t)x, (int16_t)y, 0});
+    }
+    ctx->n_tiles = (int)tiles.size();
+
+    const size_t B = (size_t)cfg->max_batch;
+    hipError_t e = hipMalloc((void **)&ctx->d_pyr, B * g.frame_stride + 256);
+    if (e == hipSuccess) e = hipMemset(ctx->d_pyr, 0, B * g.frame_stride + 256);
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_cellkey, B * g.K * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_sel, B * g.cap * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_selcount, B * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_tiles, (tiles.size() + 1) * sizeof(TileDesc));
+    if (e == hipSuccess && !tiles.empty())
+        e = hipMemcpy(ctx->d_tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        set_thread_error("orbfe_create: device allocation failed: %s", hipGetErrorString(e));
+        orbfe_destroy(ctx);
+        return ORBFE_ERR_HIP;
+    }
+    *out = ctx;
+    return ORBFE_OK;
+}
+
+void orbfe_destroy(orbfe_ctx *ctx)
+{
+    if (!ctx) return;
+    if (ctx->d_pyr) (void)hipFree(ctx->d_pyr);
+    if (ctx->d_cellkey) (void)hipFree(ctx->d_cellkey);
+    if (ctx->d_sel) (void)hipFree(ctx->d_sel);
+    if (ctx->d_selcount) (void)hipFree(ctx->d_selcount);
+    if (ctx->d_tiles) (void)hipFree(ctx->d_tiles);
+    delete ctx;
+}
+
+int orbfe_num_cells(const orbfe_ctx *ctx) { return ctx ? ctx->g.K : 0; }
+int orbfe_max_keypoints(const orbfe_ctx *ctx) { return ctx ? ctx->g.cap : 0; }
+int orbfe_num_levels(const orbfe_ctx *ctx) { return ctx ? ctx->g.L : 0; }
+
+int orbfe_level_info(const orbfe_ctx *ctx, int level, int *width, int *height, size_t *pitch,
+                     const uint8_t **d_image, size_t *frame_stride)
+{
+    if (!ctx) return ORBFE_ERR_INVALID_ARG;
+    if (level < 0 || level >= ctx->g.L) return ORBFE_ERR_INVALID_ARG;
+    if (width) *width = ctx->g.lv[level].w;
+    if (height) *height = ctx->g.lv[level].h;
+    if (pitch) *pitch = (size_t)ctx->g.lv[level].pitch;
+    if (d_image) *d_image = ctx->d_pyr + ctx->g.lv[level].offset;
+    if (frame_stride) *frame_stride = ctx->g.frame_stride;
+    return ORBFE_OK;
+}
+
+int orbfe_build_pyramid(orbfe_ctx *ctx, const uint8_t *d_gray, size_t pitch, size_t frame_stride,
+                        int n_frames, orbfe_stream_t stream)
+{
+    if (!ctx) return ORBFE_ERR_INVALID_ARG;
+    const DeviceGeom &g = ctx->g;
+    if (!d_gray || n_frames < 1 || pitch < (size_t)g.W || (n_frames > 1 && frame_stride < pitch * (size_t)g.H))
+        CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "build_pyramid: bad input geometry");
+    if (n_frames > ctx->cfg.max_batch)
+        CTX_FAIL(ctx, ORBFE_ERR_CAPACITY, "build_pyramid: n_frames %d > max_batch %d", n_frames, ctx->cfg.max_batch);
+    ORBFE_HIP_TRY(ctx->err, hipSetDevice(ctx->cfg.device));
+    const bool vec = (pitch % 4 == 0) && (frame_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_gray) & 3u) == 0);
+    {
+        dim3 grid((g.W + 255) / 256, (g.H + 3) / 4, n_frames), block(256);
+        if (vec)
+            hipLaunchKernelGGL(blur_batch_kernel<true>, grid, block, 0, S(stream), ctx->d_pyr + g.lv[0].offset,
+                               g.lv[0].pitch, g.frame_stride, d_gray, (int)pitch, frame_stride, g.W, g.H);
+        else
+            hipLaunchKernelGGL(blur_batch_kernel<false>, grid, block, 0, S(stream), ctx->d_pyr + g.lv[0].offset,
+                               g.lv[0].pitch, g.frame_stride, d_gray, (int)pitch, frame_stride, g.W, g.H);
+    }
+    for (int l = 1; l < g.L; l++) {
+        const int dw = g.lv[l].w, dh = g.lv[l].h;
+        if (dw == 0 || dh == 0) break;
+        dim3 grid((dw + 255) / 256, (dh + 3) / 4, n_frames), block(256);
+        hipLaunchKernelGGL(halfsample_batch_kernel, grid, block, 0, S(stream), ctx->d_pyr, g.frame_stride,
+                           g.lv[l - 1].offset, g.lv[l - 1].pitch, g.lv[l].offset, g.lv[l].pitch, dw, dh);
+    }
+    CTX_LAUNCH_CHECK(ctx, "build_pyramid");
+    return ORBFE_OK;
+}
+
+int orbfe_detect_batch(orbfe_ctx *ctx, int n_frames, orbfe_stream_t stream)
+{
+    if (!ctx) return ORBFE_ERR_INVALID_ARG;
+    if (n_frames < 1) CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "detect_batch: n_frames %d", n_frames);
+    if (n_frames > ctx->cfg.max_batch)
+        CTX_FAIL(ctx, ORBFE_ERR_CAPACITY, "detect_batch: n_frames %d > max_batch %d", n_frames, ctx->cfg.max_batch);
+    const DeviceGeom &g = ctx->g;
+    ORBFE_HIP_TRY(ctx->err, hipSetDevice(ctx->cfg.device));
+    ORBFE_HIP_TRY(ctx->err, hipMemsetAsync(ctx->d_cellkey, 0, (size_t)n_frames * g.K * sizeof(uint32_t), S(stream)));
+    if (ctx->n_tiles > 0)
+        hipLaunchKernelGGL(detect_tile_kernel, dim3(ctx->n_tiles, n_frames), dim3(256), 0, S(stream), g,
+                           ctx->d_pyr, ctx->d_tiles, ctx->d_cellkey);
+    CTX_LAUNCH_CHECK(ctx, "detect_batch");
+    return ORBFE_OK;
+}
+
+int orbfe_describe_batch(orbfe_ctx *ctx, int n_frames, orbfe_keypoint *d_records, int32_t *d_counts,
+                         const orbfe_soa *soa, orbfe_stream_t stream)
+{
+    if (!ctx) return ORBFE_ERR_INVALID_ARG;
+    if (!d_records || !d_counts) CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "describe_batch: null output");
+    if (n_frames < 1) CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "describe_batch: n_frames %d", n_frames);
+    if (n_frames > ctx->cfg.max_batch)
+        CTX_FAIL(ctx, ORBFE_ERR_CAPACITY, "describe_batch: n_frames %d > max_batch %d", n_frames, ctx->cfg.max_batch);
+    if ((reinterpret_cast<uintptr_t>(d_records) & 3u) || (soa && soa->d_desc && (reinterpret_cast<uintptr_t>(soa->d_desc) & 3u)))
+        CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "describe_batch: outputs must be 4-byte aligned");
+    const DeviceGeom &g = ctx->g;
+    orbfe_soa so = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (soa) so = *soa;
+    ORBFE_HIP_TRY(ctx->err, hipSetDevice(ctx->cfg.device));
+    hipLaunchKernelGGL(select_kernel, dim3(n_frames), dim3(256), 0, S(stream), g, ctx->d_cellkey, ctx->d_sel,
+                       ctx->d_selcount, d_counts, so);
+    hipLaunchKernelGGL(describe_kernel, dim3((g.cap + 3) / 4, n_frames), dim3(256), 0, S(stream), g, ctx->d_pyr,
+                       ctx->d_cellkey, ctx->d_sel, ctx->d_selcount, d_records, so);
+    CTX_LAUNCH_CHECK(ctx, "describe_batch");
+    return ORBFE_OK;
+}
+
+int orbfe_extract(orbfe_ctx *ctx, const uint8_t *d_gray, size_t pitch, size_t frame_stride,
+                  int n_frames, orbfe_keypoint *d_records, int32_t *d_counts, const orbfe_soa *soa,
+                  orbfe_stream_t stream)
+{
+    if (!ctx) return ORBFE_ERR_INVALID_ARG;
+    if (!d_records || !d_counts) CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "extract: null output");
+    int rc = orbfe_build_pyramid(ctx, d_gray, pitch, frame_stride, n_frames, stream);
+    if (rc == ORBFE_OK) rc = orbfe_detect_batch(ctx, n_frames, stream);
+    if (rc == ORBFE_OK) rc = orbfe_describe_batch(ctx, n_frames, d_records, d_counts, soa, stream);
+    return rc;
+}
+
+int orbfe_match_batch(orbfe_ctx *ctx, const orbfe_keypoint *d_records, const int32_t *d_counts, int n_frames,
+                      int mode, int window, int max_distance, int32_t *d_idx, int32_t *d_dist,
+                      orbfe_stream_t stream)
+{
+    if (!ctx) return ORBFE_ERR_INVALID_ARG;
+    if (!d_records || !d_counts || !d_idx || n_frames < 1)
+        CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "match_batch: null argument");
+    if (mode != 0 && mode != 1) CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "match_batch: mode %d", mode);
+    if (mode == 0 && window < 0) CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "match_batch: reference mode needs window >= 0");
+    if (n_frames < 2) return ORBFE_OK;
+    const int cap = ctx->g.cap;
+    dim3 grid((cap + 255) / 256, n_frames - 1), block(256);
+    if (mode == 0)
+        hipLaunchKernelGGL(match_batch_ref_kernel, grid, block, 0, S(stream), d_records, d_counts, cap,
+                           (float)window, max_distance, d_idx, d_dist);
+    else
+        hipLaunchKernelGGL(match_batch_256_kernel, grid, block, 0, S(stream), d_records, d_counts, cap, window,
+                           max_distance, d_idx, d_dist);
+    CTX_LAUNCH_CHECK(ctx, "match_batch");
+    return ORBFE_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,91 @@
+// device_common.hpp -- device helpers shared by stage_kernels.hip and batch_kernels.hip.
+#pragma once
+#include "orbfe_internal.hpp"
+
+namespace orbfe {
+
+// rBRIEF pattern, 256 rows of (Px, Py, Qx, Qy) (include/orbfe_pattern.h)
+static __constant__ int8_t c_pattern[ORBFE_PATTERN_TESTS * 4] = {ORBFE_PATTERN_VALUES};
+
+// Orientation patch half-widths, floor(sqrtf(225 - dy*dy) + 0.5) for dy = 0..15
+// (src/cuda/orb.cu:106; dy = 15 gives 0).
+static __constant__ int8_t c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 7, 5, 0};
+
+__device__ inline void patch_moments(const uint8_t *__restrict__ img, int pitch, int w, int h,
+                                     int kx, int ky, int lane, int *m10_out, int *m01_out)
+{
+    const int col = lane & 31, half = lane >> 5;
+    int m10 = 0, m01 = 0;
+    const int dx = col - 15;
+    const int tdx = kx + dx;
+    if (col < 31 && tdx > 0 && tdx < w) {
+        if (half == 0) {
+            m10 += dx * (int)img[(size_t)ky * pitch + tdx]; // centre row: no row test (:94-102)
+            for (int dy = 1; dy < 16; dy++)
+                if (ky - dy > 0 && (dx <= c_umax[dy] && -dx <= c_umax[dy])) {
+                    const int v = img[(size_t)(ky - dy) * pitch + tdx];
+                    m01 -= dy * v;
+                    m10 += dx * v;
+                }
+        } else {
+            for (int dy = 1; dy < 16; dy++)
+                if (ky + dy < h && (dx <= c_umax[dy] && -dx <= c_umax[dy])) {
+                    const int v = img[(size_t)(ky + dy) * pitch + tdx];
+                    m01 += dy * v;
+                    m10 += dx * v;
+                }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        m10 += __shfl_xor(m10, off);
+        m01 += __shfl_xor(m01, off);
+    }
+    *m10_out = m10;
+    *m01_out = m01;
+}
+
+// ------------------------------------------------------------------------------------
+// rBRIEF (orb.cu:17-75) + 32-bit "compression" (orb.cu:145-169).  One wave per keypoint.
+// In round r (0..3) lane t evaluates pattern test 64 r + t, and the 64-bit __ballot of the
+// outcomes IS descriptor bytes 8r .. 8r+7 (bit j of byte b is test 8b + j).  All 64 lanes of
+// the wave must be active when orb_describe is called.
+// ------------------------------------------------------------------------------------
+__device__ inline bool orb_border_zero(int lx, int ly, int w, int h, int radians)
+{
+    return radians ? (lx < 19 || lx > w - 20 || ly < 19 || ly > h - 20)
+                   : (lx < 17 || lx > w - 17 || ly < 17 || ly > h - 17);
+}
+
+__device__ inline void orb_describe(const uint8_t *__restrict__ img, int pitch, int lx, int ly,
+                                    float angle, int radians, int lane, uint64_t d[4])
+{
+    ORBFE_NO_CONTRACT
+    const float ang = radians ? angle : angle * ORBFE_DEG2RAD_F;
+    float a, b;
+    orbfe_sincosf(ang, &b, &a); // a = cos, b = sin
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int8_t *pt = c_pattern + 4 * (64 * r + lane);
+        const float px = (float)pt[0], py = (float)pt[1], qx = (float)pt[2], qy = (float)pt[3];
+        const float p1 = px * b, p2 = py * a, p3 = px * a, p4 = py * b;
+        const float q1 = qx * b, q2 = qy * a, q3 = qx * a, q4 = qy * b;
+        const int prow = ly + orbfe_rn_int(p1 + p2), pcol = lx + orbfe_rn_int(p3 - p4);
+        const int qrow = ly + orbfe_rn_int(q1 + q2), qcol = lx + orbfe_rn_int(q3 - q4);
+        const int t0 = img[(size_t)prow * pitch + pcol];
+        const int t1 = img[(size_t)qrow * pitch + qcol];
+        d[r] = __ballot(t0 < t1);
+    }
+}
+
+__device__ inline uint32_t orb_compress(const uint64_t d[4])
+{
+    uint32_t out = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int k = 0; k < 8; k++) out |= (uint32_t)(((d[r] >> (8 * k)) & 0xFFull) == 1ull) << (8 * r + k);
+    return out;
+}
+
+} // namespace orbfe

@@ -1,0 +1,185 @@
+// orbfe_internal.hpp -- shared by the HIP translation units of liborbfe.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/orbfe.h"
+#include "../../include/orbfe_math.h"
+#include "../../include/orbfe_pattern.h"
+
+namespace orbfe {
+
+constexpr int kWave = 64; // gfx950 wavefront
+
+// ---- error plumbing: status codes + per-thread / per-context message ------------------
+void set_thread_error(const char *fmt, ...);
+const char *thread_error();
+
+#define ORBFE_HIP_TRY(ctx_err, expr)                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            orbfe::format_error(ctx_err, "%s failed: %s (%s:%d)", #expr,                    \
+                                hipGetErrorString(e_), __FILE__, __LINE__);                 \
+            return ORBFE_ERR_HIP;                                                           \
+        }                                                                                   \
+    } while (0)
+
+void format_error(char *ctx_err, const char *fmt, ...);
+
+// ---- NMS tie-break in closed form ---------------------------------------------------
+// The reference picks, per cell, the maximum response with ties decided by the structure
+// of its kernel (src/cuda/nms.cu:105-108, :188, :201-212, :230-244, :246): lower pyramid
+// level first, then lower warp id, then lower bit-reversed lane id, then the earlier row
+// iteration of the owning thread.  We pack all of it into one
+// 27-bit key whose unsigned maximum IS that winner, so the per-cell reduction becomes an
+// order-independent max (wave reduction or atomicMax) with a deterministic result:
+//     key = score << 15 | (7 - level) << 12 | (4095 - rank)
+//     rank = ((warp_id * 32 + bitrev5(lane_id)) << 5) | row_iteration
+// score <= 16 * 255 = 4080 < 2^12; level <= 6; rank < 2^12 for every cell size <= 64.
+struct NmsGeom {
+    int c;    // cell size at this level (power of two)
+    int by;   // thread rows of the reference block: max(1, min(128 / c, c))
+};
+
+__host__ __device__ inline NmsGeom nms_geom(int cell0, int level)
+{
+    NmsGeom g;
+    g.c = cell0 >> level;
+    int t = 128 / (g.c > 0 ? g.c : 1);
+    int m = t < g.c ? t : g.c;
+    g.by = m > 1 ? m : 1;
+    return g;
+}
+
+__host__ __device__ inline uint32_t nms_key(int score, int level, int x, int y, int cell0)
+{
+    NmsGeom g = nms_geom(cell0, level);
+    int cx = x / g.c, cy = y / g.c;
+    int tx = x - g.c * cx;
+    int yoff = 3 - g.c * cy;
+    yoff = yoff > 0 ? yoff : 0;
+    int r = y - g.c * cy - yoff;
+    int ty = r % g.by, k = r / g.by;
+    int tid = tx + g.c * ty;
+    uint32_t rank = (((uint32_t)(tid >> 5) * 32u + orbfe_bitrev5((uint32_t)tid & 31u)) << 5) |
+                    (uint32_t)k;
+    return ((uint32_t)score << 15) | ((uint32_t)(7 - level) << 12) | (4095u - rank);
+}
+
+__host__ __device__ inline void nms_decode(uint32_t key, int cell_x, int cell_y, int cell0,
+                                           int *score, int *level, int *x, int *y)
+{
+    *score = (int)(key >> 15);
+    if (*score == 0) { // empty cell: SURVEY.md Appendix A, Q5
+        *level = 0;
+        *x = 0;
+        *y = 0;
+        return;
+    }
+    int l = 7 - (int)((key >> 12) & 7u);
+    uint32_t rank = 4095u - (key & 4095u);
+    int k = (int)(rank & 31u);
+    uint32_t wl = rank >> 5;
+    int tid = (int)((wl >> 5) * 32u + orbfe_bitrev5(wl & 31u));
+    NmsGeom g = nms_geom(cell0, l);
+    int tx = tid % g.c, ty = tid / g.c;
+    int yoff = 3 - g.c * cell_y;
+    yoff = yoff > 0 ? yoff : 0;
+    *level = l;
+    *x = (g.c * cell_x + tx) << l;
+    *y = (g.c * cell_y + yoff + ty + k * g.by) << l;
+}
+
+// ---- FAST ring (src/cuda/fast.cu:41-96), index i -> (dx, dy), +y down ------------------
+__host__ __device__ constexpr int ring_dx(int i)
+{
+    return i == 0 ? 0 : i == 1 ? -1 : i == 2 ? -2 : i == 3 ? -3 : i == 4 ? -3 : i == 5 ? -3
+         : i == 6 ? -2 : i == 7 ? -1 : i == 8 ? 0 : i == 9 ? 1 : i == 10 ? 2 : i == 11 ? 3
+         : i == 12 ? 3 : i == 13 ? 3 : i == 14 ? 2 : 1;
+}
+__host__ __device__ constexpr int ring_dy(int i)
+{
+    return i == 0 ? 3 : i == 1 ? 3 : i == 2 ? 2 : i == 3 ? 1 : i == 4 ? 0 : i == 5 ? -1
+         : i == 6 ? -2 : i == 7 ? -3 : i == 8 ? -3 : i == 9 ? -3 : i == 10 ? -2 : i == 11 ? -1
+         : i == 12 ? 0 : i == 13 ? 1 : i == 14 ? 2 : 3;
+}
+
+// Integer FAST score of the pixel at p (any address space), rows `pitch` apart.
+// Semantics of src/cuda/fast.cu:176-255 for an integer threshold t: darker <=> v < c - t,
+// brighter <=> v > c + t; corner <=> dark or bright mask holds a cyclic run >= arc;
+// score = max over the two labels of sum(|v - c| - t) on ALL pixels with that label.
+// The two opposite-pair prechecks (:98-124) only skip work, they never change a result
+// for arc >= 9 (a 9-run on a 16-ring covers at least one pixel of every opposite pair).
+template <typename PixelPtr>
+__device__ inline int fast_score_int(PixelPtr p, int pitch, int t, int arc)
+{
+    const int c = p[0];
+    const int lo = c - t, hi = c + t;
+    {
+        int a = p[-3], b = p[3];
+        if (a >= lo && a <= hi && b >= lo && b <= hi) return 0;
+        a = p[3 * pitch];
+        b = p[-3 * pitch];
+        if (a >= lo && a <= hi && b >= lo && b <= hi) return 0;
+    }
+    uint32_t dark = 0, bright = 0;
+    int sd = 0, sb = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int v = p[ring_dy(i) * pitch + ring_dx(i)];
+        const bool d = v < lo, b = v > hi;
+        dark |= (uint32_t)d << i;
+        bright |= (uint32_t)b << i;
+        sd += d ? (lo - v) : 0;
+        sb += b ? (v - hi) : 0;
+    }
+    if (!(orbfe_has_arc(dark, arc) | orbfe_has_arc(bright, arc))) return 0;
+    return sd > sb ? sd : sb;
+}
+
+// ---- context -----------------------------------------------------------------------
+constexpr int kMaxLevels = 16;
+constexpr int kTileW = 64, kTileH = 32; // detection tile (pixels of one level)
+
+struct LevelInfo {
+    int w, h, pitch;
+    size_t offset; // bytes from the frame base inside the pyramid buffer
+};
+
+struct TileDesc { // one detection workgroup
+    int16_t level, tx, ty, pad;
+};
+
+struct DeviceGeom { // passed by value to kernels
+    int W, H;
+    int L;        // levels built
+    int Ld;       // levels detected on
+    int cell;     // level-0 cell
+    int cells_x, cells_y, K;
+    int cap;      // records per frame
+    int threshold, arc;
+    int max_features;
+    int angle_in_radians;
+    size_t frame_stride;
+    LevelInfo lv[kMaxLevels];
+};
+
+} // namespace orbfe
+
+struct orbfe_ctx {
+    orbfe_config cfg;
+    orbfe::DeviceGeom g;
+    uint8_t *d_pyr = nullptr;       // [max_batch][frame_stride]
+    uint32_t *d_cellkey = nullptr;  // [max_batch][K]
+    int32_t *d_sel = nullptr;       // [max_batch][cap] selected cell ids, cell order
+    int32_t *d_selcount = nullptr;  // [max_batch]
+    orbfe::TileDesc *d_tiles = nullptr;
+    int n_tiles = 0;
+    char err[512] = {0};
+};

@@ -1,0 +1,554 @@
+// stage_kernels.hip -- the per-frame "stage" entry points of include/orbfe.h: drop-in
+// replacements for the free functions of the reference's src/cuda/*.cuh, with the
+// reference's buffer contracts (caller-owned pitched device buffers, any pitch).
+// gfx950 only; wave = 64 lanes.  Semantics follow SURVEY.md Appendix C; quirk numbers Qn
+// refer to its Appendix A.  These are the correctness-first forms; the throughput path is
+// batch_kernels.hip.
+#include "orbfe_internal.hpp"
+#include "device_common.hpp"
+
+namespace orbfe {
+
+static thread_local char t_err[512];
+
+void set_thread_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_err, sizeof(t_err), fmt, ap);
+    va_end(ap);
+}
+const char *thread_error() { return t_err; }
+
+void format_error(char *ctx_err, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ctx_err ? ctx_err : t_err, 512, fmt, ap);
+    va_end(ap);
+}
+
+// ------------------------------------------------------------------------------------
+// a2  3x3 Gaussian with the reference's 32-column seams (gaussian_blur_3x3.cu:15-53)
+// One thread = one output pixel; rows 0, h-2, h-1 are written as 0 (Q1).
+// ------------------------------------------------------------------------------------
+__global__ void blur3x3_px_kernel(uint8_t *__restrict__ dst, int dst_pitch,
+                                  const uint8_t *__restrict__ src, int src_pitch, int w, int h)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= w || y >= h) return;
+    uint8_t *o = dst + (size_t)y * dst_pitch + x;
+    if (y == 0 || y >= h - 2) {
+        *o = 0;
+        return;
+    }
+    const int xl = ((x & 31) == 0) ? x : x - 1;
+    const int xr = ((x & 31) == 31 || x == w - 1) ? x : x + 1;
+    const uint8_t *ra = src + (size_t)(y - 1) * src_pitch;
+    const uint8_t *rb = ra + src_pitch;
+    const uint8_t *rc = rb + src_pitch;
+    const int s = 2 * ra[x] + 4 * rb[x] + 2 * rc[x] + ra[xl] + ra[xr] + 2 * rb[xl] + 2 * rb[xr] +
+                  rc[xl] + rc[xr];
+    *o = (uint8_t)((s + 8) >> 4); // == floor(s / 16 + 0.5), s >= 0
+}
+
+// a3  2x2 box halving (pyramid.cu:6-29)
+__global__ void halfsample_px_kernel(const uint8_t *__restrict__ src, int src_pitch,
+                                     uint8_t *__restrict__ dst, int dst_pitch, int dw, int dh)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= dw || y >= dh) return;
+    const uint8_t *t = src + (size_t)(2 * y) * src_pitch + 2 * x;
+    const uint8_t *b = t + src_pitch;
+    dst[(size_t)y * dst_pitch + x] = (uint8_t)(((unsigned)t[0] + t[1] + b[0] + b[1]) >> 2);
+}
+
+// a4  corner LUT (fast.cu:11-39): cyclic run of >= min_arc ones in the 16-bit mask
+__global__ void fast_lut_kernel(uint8_t *__restrict__ lut, int min_arc)
+{
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= 65536u) return;
+    const uint32_t dup = m | (m << 16);
+    const uint32_t want = min_arc >= 32 ? 0xFFFFFFFFu : ((1u << min_arc) - 1u);
+    int hit = 0;
+    if (min_arc <= 16)
+        for (int s = 0; s < 16; s++) hit |= (((dup >> s) & want) == want);
+    lut[m] = (uint8_t)hit;
+}
+
+// a5  corner response, float arithmetic as in fast.cu:150-287 (any float threshold)
+__global__ void fast_response_px_kernel(int w, int h, int pitch, const uint8_t *__restrict__ img,
+                                        int hb, int vb, const uint8_t *__restrict__ lut,
+                                        float threshold, int resp_pitch,
+                                        float *__restrict__ resp)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= w || y >= h) return;
+    float out = 0.0f;
+    if (x >= hb && y >= vb && x < w - hb && y < h - vb) {
+        const uint8_t *p = img + (size_t)y * pitch + x;
+        const float c = (float)p[0];
+        const float ct = c + threshold, c_t = c - threshold;
+        float a = (float)p[-3], b = (float)p[3];
+        bool similar = !(a < c_t) && !(b < c_t) && !(ct < a) && !(ct < b);
+        if (!similar) {
+            a = (float)p[3 * pitch];
+            b = (float)p[-3 * pitch];
+            similar = !(a < c_t) && !(b < c_t) && !(ct < a) && !(ct < b);
+        }
+        if (!similar) {
+            uint32_t dark = 0, bright = 0;
+            float px[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                px[i] = (float)p[ring_dy(i) * pitch + ring_dx(i)];
+                dark |= (uint32_t)(px[i] < c_t) << i;
+                bright |= (uint32_t)(ct < px[i]) << i;
+            }
+            if (lut[dark] | lut[bright]) {
+                float rb = 0.0f, rd = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const float ad = fabsf(px[i] - c) - threshold;
+                    rd += (dark >> i & 1u) ? ad : 0.0f;
+                    rb += (bright >> i & 1u) ? ad : 0.0f;
+                }
+                out = fmaxf(rb, rd);
+            }
+        }
+    }
+    resp[(size_t)y * resp_pitch + x] = out;
+}
+
+// a6  grid NMS over all levels (nms.cu:86-296): one wave per level-0 cell.  The wave walks
+// the cell's pixels on every level, keeps the unsigned maximum of nms_key() and decodes it.
+struct NmsLevels {
+    int n;
+    int w[8], h[8], pitch[8]; // pitch in floats
+    const float *resp[8];
+};
+
+__global__ void grid_nms_kernel(NmsLevels lv, int cell0, int cells_x, int K,
+                                float *__restrict__ d_pos, float *__restrict__ d_score,
+                                int *__restrict__ d_level)
+{
+    const int lane = threadIdx.x & 63;
+    const int cell = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (cell >= K) return; // whole wave
+    const int cx = cell % cells_x, cy = cell / cells_x;
+    uint32_t best = 0;
+    for (int l = 0; l < lv.n; l++) {
+        const int c = cell0 >> l;
+        if (c == 0) break;
+        const int W = lv.w[l], H = lv.h[l], P = lv.pitch[l];
+        const float *R = lv.resp[l];
+        for (int i = lane; i < c * c; i += 64) {
+            const int x = c * cx + (i % c), y = c * cy + (i / c);
+            if (x < 3 || y < 3 || x >= W - 3 || y >= H - 3) continue;
+            const float *q = R + (size_t)y * P + x;
+            const float v = q[0];
+            if (!(v > 0.0f)) continue;
+            const bool is_max = v > q[-P] && v > q[-P + 1] && v > q[1] && v > q[P + 1] &&
+                                v > q[P] && v > q[P - 1] && v > q[-1] && v > q[-P - 1];
+            if (!is_max) continue;
+            const uint32_t key = nms_key((int)v, l, x, y, cell0);
+            best = key > best ? key : best;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)best, off);
+        best = o > best ? o : best;
+    }
+    if (lane == 0) {
+        int s, l, x, y;
+        nms_decode(best, cx, cy, cell0, &s, &l, &x, &y);
+        d_score[cell] = (float)s;
+        d_pos[2 * cell] = (float)x;
+        d_pos[2 * cell + 1] = (float)y;
+        d_level[cell] = l;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// a8  intensity-centroid orientation (orb.cu:77-142).  One wave per keypoint: lane =
+// patch column (0..30) + 32 * half; half 0 sums the rows above and the centre row, half 1
+// the rows below.  Integer sums (exact), wave add-reduction, deterministic atan2f.
+// ------------------------------------------------------------------------------------
+__global__ void fast_angle_kernel(float *__restrict__ d_angle, const float *__restrict__ d_pos,
+                                  const uint8_t *__restrict__ img, int pitch, int w, int h, int n)
+{
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (idx >= n) return;
+    const int kx = (int)floor((double)d_pos[2 * idx] + 0.5); // double, as orb.cu:86-87
+    const int ky = (int)floor((double)d_pos[2 * idx + 1] + 0.5);
+    int m10 = 0, m01 = 0;
+    // a keypoint the detector produced is >= 3 px inside; an arbitrary caller position may
+    // not be: rows outside the image are skipped instead of read (the reference would read
+    // out of bounds for the centre row).
+    if (ky >= 0 && ky < h) patch_moments(img, pitch, w, h, kx, ky, lane, &m10, &m01);
+    if (lane == 0) d_angle[idx] = orbfe_atan2f((float)m01, (float)m10);
+}
+
+// ------------------------------------------------------------------------------------
+// a9 + a10  rBRIEF (orb.cu:17-75) + 32-bit "compression" (orb.cu:145-169).
+// One wave per keypoint.  In round r (0..3) lane t evaluates pattern test 64 r + t, and the
+// 64-bit __ballot of the outcomes IS descriptor bytes 8r .. 8r+7 (bit j of byte b is test
+// 8b + j).  No shared memory, no byte assembly.
+// ------------------------------------------------------------------------------------
+__global__ void calc_orb_kernel(const float *__restrict__ d_angle, const float *__restrict__ d_pos,
+                                uint8_t *__restrict__ d_desc, uint32_t *__restrict__ d_desc32,
+                                const uint8_t *__restrict__ img, int pitch, int w, int h, int n,
+                                int radians)
+{
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (idx >= n) return;
+    const int lx = (int)(short)d_pos[2 * idx], ly = (int)(short)d_pos[2 * idx + 1];
+    uint64_t d[4] = {0, 0, 0, 0};
+    if (!orb_border_zero(lx, ly, w, h, radians)) orb_describe(img, pitch, lx, ly, d_angle[idx], radians, lane, d);
+    if (lane < 4) reinterpret_cast<uint64_t *>(d_desc + (size_t)idx * 32)[lane] = d[lane];
+    if (lane == 0 && d_desc32) d_desc32[idx] = orb_compress(d);
+}
+
+// ------------------------------------------------------------------------------------
+// a11  reference matcher (post_processing.cu:92-200).  Thread i = prev keypoint i; its
+// "tid" in the reference's 32-thread block is i & 31.  Curr keypoints are staged in LDS in
+// tiles of 32; inside a tile of m entries thread tid visits j = (s + tid) % m, s = 0..m-1,
+// and skips the tile when tid >= m (Q8).  First strictly smaller distance wins.
+// ------------------------------------------------------------------------------------
+__global__ void match_ref_kernel(const float *__restrict__ pos_prev,
+                                 const uint32_t *__restrict__ desc_prev, int n_prev,
+                                 const float *__restrict__ pos_curr,
+                                 const uint32_t *__restrict__ desc_curr, int n_curr, float win,
+                                 int max_ham, int32_t *__restrict__ match_idx,
+                                 int32_t *__restrict__ num_matched)
+{
+    __shared__ float s_x[32], s_y[32];
+    __shared__ uint32_t s_d[32];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tid = i & 31;
+    const bool live = i < n_prev;
+    float px = 0.f, py = 0.f;
+    uint32_t d = 0;
+    if (live) {
+        px = pos_prev[2 * i];
+        py = pos_prev[2 * i + 1];
+        d = desc_prev[i];
+    }
+    int best = 9999999, pair = -1;
+    for (int base = 0; base < n_curr; base += 32) {
+        __syncthreads();
+        if (threadIdx.x < 32 && base + (int)threadIdx.x < n_curr) {
+            s_x[threadIdx.x] = pos_curr[2 * (base + threadIdx.x)];
+            s_y[threadIdx.x] = pos_curr[2 * (base + threadIdx.x) + 1];
+            s_d[threadIdx.x] = desc_curr[base + threadIdx.x];
+        }
+        __syncthreads();
+        const int m = (base + 32 >= n_curr) ? n_curr - base : 32;
+        if (live && tid < m) {
+            int j = tid; // (s + tid) % m for s = 0
+            for (int s = 0; s < m; s++) {
+                if (fabsf(px - s_x[j]) <= win && fabsf(py - s_y[j]) <= win) {
+                    const int hd = __popc(d ^ s_d[j]);
+                    if (hd < max_ham && hd < best) {
+                        best = hd;
+                        pair = base + j;
+                    }
+                }
+                j = (j + 1 == m) ? 0 : j + 1;
+            }
+        }
+    }
+    if (live) match_idx[i] = pair;
+    const uint64_t hit = __ballot(live && pair >= 0);
+    if ((threadIdx.x & 63) == 0 && hit) atomicAdd(num_matched, (int)__popcll(hit));
+}
+
+// ------------------------------------------------------------------------------------
+// EXT  brute-force 256-bit Hamming.  Thread = one query (8 dwords in registers); B is
+// staged through LDS in tiles and read as wave-uniform (broadcast) b128 pairs.
+// ------------------------------------------------------------------------------------
+constexpr int kMatchTile = 256;
+
+__global__ void __launch_bounds__(256)
+match256_kernel(const uint8_t *__restrict__ descA, const float *__restrict__ posA, int nA,
+                const uint8_t *__restrict__ descB, const float *__restrict__ posB, int nB,
+                int window, int max_dist, int32_t *__restrict__ out_idx,
+                int32_t *__restrict__ out_dist)
+{
+    __shared__ uint4 s_b[kMatchTile * 2];
+    __shared__ float2 s_p[kMatchTile];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < nA;
+    uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+    float ax = 0.f, ay = 0.f;
+    if (live) {
+        const uint4 *pa = reinterpret_cast<const uint4 *>(descA + (size_t)i * 32);
+        a0 = pa[0];
+        a1 = pa[1];
+        if (window >= 0) {
+            ax = posA[2 * i];
+            ay = posA[2 * i + 1];
+        }
+    }
+    const float win = (float)window;
+    int best = 1 << 30, best_j = -1;
+    for (int base = 0; base < nB; base += kMatchTile) {
+        const int m = min(kMatchTile, nB - base);
+        __syncthreads();
+        for (int t = threadIdx.x; t < 2 * m; t += blockDim.x)
+            s_b[t] = reinterpret_cast<const uint4 *>(descB + (size_t)base * 32)[t];
+        if (window >= 0)
+            for (int t = threadIdx.x; t < m; t += blockDim.x)
+                s_p[t] = make_float2(posB[2 * (base + t)], posB[2 * (base + t) + 1]);
+        __syncthreads();
+        for (int j = 0; j < m; j++) {
+            const uint4 b0 = s_b[2 * j], b1 = s_b[2 * j + 1];
+            int dist = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) +
+                       __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) +
+                       __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+            if (window >= 0) {
+                const float2 pb = s_p[j];
+                if (fabsf(ax - pb.x) > win || fabsf(ay - pb.y) > win) dist = 1 << 30;
+            }
+            if (dist < best) { // strict: ties keep the lower index
+                best = dist;
+                best_j = base + j;
+            }
+        }
+    }
+    if (live) {
+        const bool ok = best_j >= 0 && best <= max_dist;
+        out_idx[i] = ok ? best_j : -1;
+        if (out_dist) out_dist[i] = ok ? best : -1;
+    }
+}
+
+} // namespace orbfe
+
+// ======================================================================================
+// C ABI
+// ======================================================================================
+using namespace orbfe;
+
+static inline hipStream_t S(orbfe_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static int launch_status(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_thread_error("%s launch failed: %s", what, hipGetErrorString(e));
+        return ORBFE_ERR_HIP;
+    }
+    return ORBFE_OK;
+}
+
+#define ARG_CHECK(cond)                                                                     \
+    do {                                                                                    \
+        if (!(cond)) {                                                                      \
+            set_thread_error("%s: invalid argument: %s", __func__, #cond);                  \
+            return ORBFE_ERR_INVALID_ARG;                                                   \
+        }                                                                                   \
+    } while (0)
+
+extern "C" {
+
+int orbfe_version(void) { return ORBFE_VERSION; }
+
+int orbfe_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int orbfe_load_pattern(void) { return ORBFE_OK; }
+
+int orbfe_gaussian_blur_3x3(unsigned char *d_blurred, int blurred_pitch,
+                            const unsigned char *d_image, int image_pitch, int w, int h,
+                            orbfe_stream_t stream)
+{
+    ARG_CHECK(d_blurred && d_image && w > 0 && h > 0 && blurred_pitch >= w && image_pitch >= w);
+    dim3 block(64, 4), grid((w + 63) / 64, (h + 3) / 4);
+    hipLaunchKernelGGL(blur3x3_px_kernel, grid, block, 0, S(stream), d_blurred, blurred_pitch,
+                       d_image, image_pitch, w, h);
+    return launch_status("gaussian_blur_3x3");
+}
+
+int orbfe_pyramid_create_levels(const orbfe_pyramid_level *lv, int n_levels,
+                                orbfe_stream_t stream)
+{
+    ARG_CHECK(lv && n_levels >= 1);
+    for (int i = 1; i < n_levels; i++) {
+        ARG_CHECK(lv[i].image && lv[i - 1].image);
+        ARG_CHECK(lv[i].image_width == lv[i - 1].image_width / 2 &&
+                  lv[i].image_height == lv[i - 1].image_height / 2);
+        ARG_CHECK(lv[i].image_pitch >= lv[i].image_width);
+        const int dw = (int)lv[i].image_width, dh = (int)lv[i].image_height;
+        if (dw == 0 || dh == 0) continue;
+        dim3 block(64, 4), grid((dw + 63) / 64, (dh + 3) / 4);
+        hipLaunchKernelGGL(halfsample_px_kernel, grid, block, 0, S(stream), lv[i - 1].image,
+                           (int)lv[i - 1].image_pitch, lv[i].image, (int)lv[i].image_pitch, dw, dh);
+    }
+    return launch_status("pyramid_create_levels");
+}
+
+int orbfe_fast_calculate_lut(unsigned char *d_lut, int min_arc, orbfe_stream_t stream)
+{
+    ARG_CHECK(d_lut && min_arc >= 1 && min_arc <= 16);
+    hipLaunchKernelGGL(fast_lut_kernel, dim3(256), dim3(256), 0, S(stream), d_lut, min_arc);
+    return launch_status("fast_calculate_lut");
+}
+
+int orbfe_fast_calc_corner_response(int w, int h, int pitch, const unsigned char *d_image, int hb,
+                                    int vb, const unsigned char *d_lut, float threshold,
+                                    int min_arc_length, int score, int resp_pitch_elems,
+                                    float *d_response, orbfe_stream_t stream)
+{
+    (void)min_arc_length; // unused by the reference kernel too (fast.cu:160): the LUT decides
+    ARG_CHECK(d_image && d_lut && d_response && w > 0 && h > 0 && pitch >= w &&
+              resp_pitch_elems >= w && hb >= 3 && vb >= 3);
+    if (score != ORBFE_SUM_OF_ABS_DIFF_ON_ARC) {
+        set_thread_error("fast_calc_corner_response: only SUM_OF_ABS_DIFF_ON_ARC is on the "
+                         "reference's live path (defines.h:9)");
+        return ORBFE_ERR_UNSUPPORTED;
+    }
+    dim3 block(64, 4), grid((w + 63) / 64, (h + 3) / 4);
+    hipLaunchKernelGGL(fast_response_px_kernel, grid, block, 0, S(stream), w, h, pitch, d_image, hb,
+                       vb, d_lut, threshold, resp_pitch_elems, d_response);
+    return launch_status("fast_calc_corner_response");
+}
+
+int orbfe_grid_nms(const orbfe_pyramid_level *lv, int n_levels, float *d_pos, float *d_score,
+                   int *d_level, orbfe_stream_t stream)
+{
+    ARG_CHECK(lv && n_levels >= 1 && d_pos && d_score && d_level);
+    if (n_levels > 6) { // 32 >> 6 == 0: the reference divides by zero (nms.cu:273), Q12
+        set_thread_error("grid_nms: at most 6 levels with 32-pixel cells");
+        return ORBFE_ERR_UNSUPPORTED;
+    }
+    NmsLevels L;
+    L.n = n_levels;
+    for (int i = 0; i < n_levels; i++) {
+        ARG_CHECK(lv[i].response && lv[i].response_pitch >= lv[i].image_width * sizeof(float));
+        L.w[i] = (int)lv[i].image_width;
+        L.h[i] = (int)lv[i].image_height;
+        L.pitch[i] = (int)(lv[i].response_pitch / sizeof(float));
+        L.resp[i] = lv[i].response;
+    }
+    const int W = (int)lv[0].image_width, H = (int)lv[0].image_height;
+    const int cx = (W + 31) / 32, cy = (H + 31) / 32, K = cx * cy;
+    hipLaunchKernelGGL(grid_nms_kernel, dim3((K + 3) / 4), dim3(256), 0, S(stream), L, 32, cx, K,
+                       d_pos, d_score, d_level);
+    return launch_status("grid_nms");
+}
+
+int orbfe_detect(const orbfe_pyramid_level *lv, int n_levels, const unsigned char *d_lut,
+                 float threshold, float *d_pos, float *d_score, int *d_level,
+                 orbfe_stream_t stream)
+{
+    ARG_CHECK(lv && n_levels >= 1);
+    for (int i = 0; i < n_levels; i++) {
+        int rc = orbfe_fast_calc_corner_response(
+            (int)lv[i].image_width, (int)lv[i].image_height, (int)lv[i].image_pitch, lv[i].image, 3,
+            3, d_lut, threshold, 0, ORBFE_SUM_OF_ABS_DIFF_ON_ARC,
+            (int)(lv[i].response_pitch / sizeof(float)), lv[i].response, stream);
+        if (rc != ORBFE_OK) return rc;
+    }
+    return orbfe_grid_nms(lv, n_levels, d_pos, d_score, d_level, stream);
+}
+
+int orbfe_compute_fast_angle(float *d_angle, const float *d_pos, const unsigned char *d_image,
+                             int pitch, int w, int h, int n, orbfe_stream_t stream)
+{
+    ARG_CHECK(d_angle && d_pos && d_image && w > 0 && h > 0 && pitch >= w && n >= 0);
+    if (n == 0) return ORBFE_OK;
+    hipLaunchKernelGGL(fast_angle_kernel, dim3((n + 3) / 4), dim3(256), 0, S(stream), d_angle, d_pos,
+                       d_image, pitch, w, h, n);
+    return launch_status("compute_fast_angle");
+}
+
+int orbfe_calc_orb(const float *d_angle, const float *d_pos, unsigned char *d_desc_tmp,
+                   uint32_t *d_desc, const unsigned char *d_image, int pitch, int w, int h, int n,
+                   orbfe_stream_t stream)
+{
+    ARG_CHECK(d_angle && d_pos && d_desc_tmp && d_image && w > 0 && h > 0 && pitch >= w && n >= 0);
+    ARG_CHECK((reinterpret_cast<uintptr_t>(d_desc_tmp) & 7u) == 0);
+    if (n == 0) return ORBFE_OK;
+    hipLaunchKernelGGL(calc_orb_kernel, dim3((n + 3) / 4), dim3(256), 0, S(stream), d_angle, d_pos,
+                       d_desc_tmp, d_desc, d_image, pitch, w, h, n, 0);
+    return launch_status("calc_orb");
+}
+
+int orbfe_match_keypoints(const float *d_pos_prev, const uint32_t *d_desc_prev, int n_prev,
+                          const float *d_pos_curr, const uint32_t *d_desc_curr, int n_curr,
+                          int max_px, int max_ham, int32_t *d_match_idx, int32_t *d_num_matched,
+                          orbfe_stream_t stream)
+{
+    ARG_CHECK(n_prev >= 0 && n_curr >= 0 && d_num_matched);
+    hipError_t e = hipMemsetAsync(d_num_matched, 0, sizeof(int32_t), S(stream));
+    if (e != hipSuccess) {
+        set_thread_error("match_keypoints: hipMemsetAsync: %s", hipGetErrorString(e));
+        return ORBFE_ERR_HIP;
+    }
+    if (n_prev == 0) return ORBFE_OK;
+    ARG_CHECK(d_pos_prev && d_desc_prev && d_match_idx && (n_curr == 0 || (d_pos_curr && d_desc_curr)));
+    hipLaunchKernelGGL(match_ref_kernel, dim3((n_prev + 255) / 256), dim3(256), 0, S(stream),
+                       d_pos_prev, d_desc_prev, n_prev, d_pos_curr, d_desc_curr, n_curr,
+                       (float)max_px, max_ham, d_match_idx, d_num_matched);
+    return launch_status("match_keypoints");
+}
+
+int orbfe_match256(const unsigned char *d_descA, const float *d_posA, int nA,
+                   const unsigned char *d_descB, const float *d_posB, int nB, int window,
+                   int max_distance, int32_t *d_idx, int32_t *d_dist, orbfe_stream_t stream)
+{
+    ARG_CHECK(nA >= 0 && nB >= 0);
+    if (nA == 0) return ORBFE_OK;
+    ARG_CHECK(d_descA && d_idx && (nB == 0 || d_descB));
+    ARG_CHECK(window < 0 || (d_posA && (nB == 0 || d_posB)));
+    ARG_CHECK((reinterpret_cast<uintptr_t>(d_descA) & 15u) == 0 &&
+              (reinterpret_cast<uintptr_t>(d_descB) & 15u) == 0);
+    hipLaunchKernelGGL(match256_kernel, dim3((nA + 255) / 256), dim3(256), 0, S(stream), d_descA,
+                       d_posA, nA, d_descB, d_posB, nB, window, max_distance, d_idx, d_dist);
+    return launch_status("match256");
+}
+
+int orbfe_memcpy_d2h(void *dst, const void *d_src, size_t bytes, orbfe_stream_t stream)
+{
+    hipError_t e = hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, S(stream));
+    if (e == hipSuccess) e = hipStreamSynchronize(S(stream));
+    if (e != hipSuccess) {
+        set_thread_error("memcpy_d2h: %s", hipGetErrorString(e));
+        return ORBFE_ERR_HIP;
+    }
+    return ORBFE_OK;
+}
+
+int orbfe_memcpy_h2d(void *d_dst, const void *src, size_t bytes, orbfe_stream_t stream)
+{
+    hipError_t e = hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, S(stream));
+    if (e == hipSuccess) e = hipStreamSynchronize(S(stream));
+    if (e != hipSuccess) {
+        set_thread_error("memcpy_h2d: %s", hipGetErrorString(e));
+        return ORBFE_ERR_HIP;
+    }
+    return ORBFE_OK;
+}
+
+int orbfe_stream_sync(orbfe_stream_t stream)
+{
+    hipError_t e = hipStreamSynchronize(S(stream));
+    if (e != hipSuccess) {
+        set_thread_error("stream_sync: %s", hipGetErrorString(e));
+        return ORBFE_ERR_HIP;
+    }
+    return ORBFE_OK;
+}
+
+} // extern "C"

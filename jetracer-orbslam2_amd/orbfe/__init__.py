@@ -1,0 +1,203 @@
+"""orbfe -- Python binding (ctypes) of liborbfe.so, the MI355X-native ORB front end.
+
+The product is the HIP library behind the C ABI in include/orbfe.h; this module only loads
+it and declares the signatures, for the tests and bench.  There is no CPU fallback: if the
+library is missing, `lib()` raises.  Function names mirror the reference's free functions
+(src/cuda/*.cuh of dsvua/jetracer-orbslam2): gaussian_blur_3x3, pyramid_create_levels,
+fast_gpu_calculate_lut -> fast_calculate_lut, fast_gpu_calc_corner_response ->
+fast_calc_corner_response, grid_nms, detect, compute_fast_angle, calc_orb, match_keypoints.
+All pointer arguments are raw device addresses (ints), e.g. torch.Tensor.data_ptr().
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(PKG_DIR, "liborbfe.so")
+
+OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE, ERR_CAPACITY = range(6)
+SUM_OF_ABS_DIFF_ALL, SUM_OF_ABS_DIFF_ON_ARC, MAX_THRESHOLD = 0, 1, 2
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("score", "<f4"), ("level", "<i4"),
+                           ("angle", "<f4"), ("desc", "u1", (32,))])
+assert KEYPOINT_DTYPE.itemsize == 52
+
+
+class OrbfeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("orbfe error %d: %s" % (code, msg))
+        self.code = code
+
+
+class PyramidLevel(C.Structure):  # orbfe_pyramid_level == reference pyramid_t
+    _fields_ = [("image_width", C.c_size_t), ("image_height", C.c_size_t),
+                ("image_pitch", C.c_size_t), ("image", C.c_void_p),
+                ("response_pitch", C.c_size_t), ("response", C.c_void_p)]
+
+
+class Config(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("levels", C.c_int32),
+                ("cell", C.c_int32), ("fast_threshold", C.c_int32), ("min_arc", C.c_int32),
+                ("max_features", C.c_int32), ("angle_in_radians", C.c_int32),
+                ("max_batch", C.c_int32), ("device", C.c_int32)]
+
+
+class Soa(C.Structure):
+    _fields_ = [("d_pos", C.c_void_p), ("d_score", C.c_void_p), ("d_level", C.c_void_p),
+                ("d_angle", C.c_void_p), ("d_desc", C.c_void_p), ("d_desc32", C.c_void_p)]
+
+
+_SIGS = {
+    "orbfe_version": (C.c_int, []),
+    "orbfe_device_count": (C.c_int, []),
+    "orbfe_load_pattern": (C.c_int, []),
+    "orbfe_gaussian_blur_3x3": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                          C.c_int, C.c_void_p]),
+    "orbfe_pyramid_create_levels": (C.c_int, [C.POINTER(PyramidLevel), C.c_int, C.c_void_p]),
+    "orbfe_fast_calculate_lut": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "orbfe_fast_calc_corner_response": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                                  C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_int,
+                                                  C.c_int, C.c_void_p, C.c_void_p]),
+    "orbfe_grid_nms": (C.c_int, [C.POINTER(PyramidLevel), C.c_int, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p]),
+    "orbfe_detect": (C.c_int, [C.POINTER(PyramidLevel), C.c_int, C.c_void_p, C.c_float,
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "orbfe_compute_fast_angle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, C.c_void_p]),
+    "orbfe_calc_orb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "orbfe_match_keypoints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
+    "orbfe_match256": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                 C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "orbfe_default_config": (None, [C.POINTER(Config), C.c_int, C.c_int]),
+    "orbfe_create": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
+    "orbfe_destroy": (None, [C.c_void_p]),
+    "orbfe_last_error": (C.c_char_p, [C.c_void_p]),
+    "orbfe_num_cells": (C.c_int, [C.c_void_p]),
+    "orbfe_max_keypoints": (C.c_int, [C.c_void_p]),
+    "orbfe_num_levels": (C.c_int, [C.c_void_p]),
+    "orbfe_level_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                   C.POINTER(C.c_size_t), C.POINTER(C.c_void_p),
+                                   C.POINTER(C.c_size_t)]),
+    "orbfe_build_pyramid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int,
+                                      C.c_void_p]),
+    "orbfe_detect_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "orbfe_describe_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.POINTER(Soa), C.c_void_p]),
+    "orbfe_extract": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int,
+                                C.c_void_p, C.c_void_p, C.POINTER(Soa), C.c_void_p]),
+    "orbfe_match_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "orbfe_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "orbfe_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "orbfe_stream_sync": (C.c_int, [C.c_void_p]),
+}
+
+EXPORTS = tuple(_SIGS)  # every symbol include/orbfe.h declares
+
+_lib = None
+
+
+def lib():
+    """Load liborbfe.so; raise if it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OrbfeError(-1, "liborbfe.so not found at %s: build it with "
+                                 "`python -c 'import __graft_entry__ as g; g.build()'` or "
+                                 "`make -C jetracer-orbslam2_amd/csrc` (needs hipcc; there is "
+                                 "no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(code, ctx=None):
+    if code != OK:
+        msg = lib().orbfe_last_error(ctx)
+        raise OrbfeError(code, msg.decode() if msg else "")
+
+
+def make_levels(images, responses=None):
+    """images/responses: lists of (device_ptr, width, height, pitch_bytes)."""
+    arr = (PyramidLevel * len(images))()
+    for i, (ptr, w, h, pitch) in enumerate(images):
+        rp, rpitch = (0, 0)
+        if responses is not None:
+            rp, _, _, rpitch = responses[i]
+        arr[i] = PyramidLevel(w, h, pitch, ptr, rpitch, rp)
+    return arr
+
+
+class Context:
+    """RAII wrapper of orbfe_ctx (batch API)."""
+
+    def __init__(self, width, height, levels=1, cell=32, fast_threshold=13, min_arc=12,
+                 max_features=0, angle_in_radians=0, max_batch=1, device=0):
+        L = lib()
+        self.cfg = Config(width, height, levels, cell, fast_threshold, min_arc, max_features,
+                          angle_in_radians, max_batch, device)
+        h = C.c_void_p()
+        check(L.orbfe_create(C.byref(self.cfg), C.byref(h)))
+        self.handle = h
+        self.K = L.orbfe_num_cells(h)
+        self.cap = L.orbfe_max_keypoints(h)
+        self.levels = L.orbfe_num_levels(h)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().orbfe_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def level_info(self, level):
+        w, h = C.c_int(), C.c_int()
+        pitch, fs = C.c_size_t(), C.c_size_t()
+        ptr = C.c_void_p()
+        check(lib().orbfe_level_info(self.handle, level, C.byref(w), C.byref(h), C.byref(pitch),
+                                     C.byref(ptr), C.byref(fs)), self.handle)
+        return w.value, h.value, pitch.value, ptr.value or 0, fs.value
+
+    def build_pyramid(self, d_gray, pitch, frame_stride, n_frames, stream=0):
+        check(lib().orbfe_build_pyramid(self.handle, d_gray, pitch, frame_stride, n_frames, stream),
+              self.handle)
+
+    def detect_batch(self, n_frames, stream=0):
+        check(lib().orbfe_detect_batch(self.handle, n_frames, stream), self.handle)
+
+    def describe_batch(self, n_frames, d_records, d_counts, soa=None, stream=0):
+        check(lib().orbfe_describe_batch(self.handle, n_frames, d_records, d_counts,
+                                         C.byref(soa) if soa is not None else None, stream),
+              self.handle)
+
+    def extract(self, d_gray, pitch, frame_stride, n_frames, d_records, d_counts, soa=None,
+                stream=0):
+        check(lib().orbfe_extract(self.handle, d_gray, pitch, frame_stride, n_frames, d_records,
+                                  d_counts, C.byref(soa) if soa is not None else None, stream),
+              self.handle)
+
+    def match_batch(self, d_records, d_counts, n_frames, mode, window, max_distance, d_idx,
+                    d_dist=None, stream=0):
+        check(lib().orbfe_match_batch(self.handle, d_records, d_counts, n_frames, mode, window,
+                                      max_distance, d_idx, d_dist, stream), self.handle)
+
+    def read_level(self, level, frame=0, stream=0):
+        """Copy one pyramid level of one frame to a numpy array [h, w] (harness helper)."""
+        w, h, pitch, ptr, fs = self.level_info(level)
+        if w == 0 or h == 0:
+            return np.zeros((h, w), np.uint8)
+        buf = np.empty((h, pitch), np.uint8)
+        check(lib().orbfe_memcpy_d2h(buf.ctypes.data, ptr + frame * fs, h * pitch, stream))
+        return buf[:, :w].copy()

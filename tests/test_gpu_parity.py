@@ -1,0 +1,475 @@
+"""GPU parity tests: every HIP entry point of include/orbfe.h against the CPU oracle on the
+same seeded inputs, called through the C ABI (ctypes).  Bit-exact: integer / byte / index
+outputs must be equal; float outputs (scores, positions, angles) are compared by their bit
+patterns (tolerance 0), because the build owns the deterministic math on both sides
+(include/orbfe_math.h).  The oracle itself is unpinned by the reference (it has no tests);
+see oracle/orbfe_oracle.h.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from orbfe import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def stream(torch):
+    return torch.cuda.current_stream().cuda_stream
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def pitched(torch, img, pitch):
+    h, w = img.shape
+    buf = np.full((h, pitch), 0xA5, np.uint8)
+    buf[:, :w] = img
+    return dev(torch, buf)
+
+
+FRAMES = {
+    "rects": lambda w, h: synth.frame(w, h, 1, "rects"),
+    "dense": lambda w, h: synth.frame(w, h, 2, "rects", **synth.DENSE),
+    "uniform": lambda w, h: synth.frame(w, h, 3, "uniform"),
+    "const": lambda w, h: synth.frame(w, h, 0, "const"),
+    "checker": lambda w, h: synth.frame(w, h, 0, "checker"),
+}
+
+
+# ------------------------------------------------------------------ a2 blur
+@pytest.mark.parametrize("w,h,extra", [(640, 480, 0), (848, 480, 0), (37, 19, 5), (33, 5, 3),
+                                        (64, 3, 0), (8, 8, 1), (95, 40, 0), (1280, 720, 0)])
+def test_blur_stage(gpu, oracle_mod, w, h, extra):
+    torch, orbfe = gpu
+    img = synth.frame(w, h, 7, "uniform")
+    src = pitched(torch, img, w + extra)
+    dst = torch.full((h, w + extra + 2), 0x5A, dtype=torch.uint8, device="cuda")
+    orbfe.check(orbfe.lib().orbfe_gaussian_blur_3x3(dst.data_ptr(), w + extra + 2, src.data_ptr(),
+                                                    w + extra, w, h, stream(torch)))
+    got = dst.cpu().numpy()
+    np.testing.assert_array_equal(got[:, :w], oracle_mod.gaussian_blur_3x3(img))
+    assert (got[:, w:] == 0x5A).all(), "blur wrote outside the image width"
+
+
+# ------------------------------------------------------------------ a3 pyramid
+@pytest.mark.parametrize("w,h,levels", [(640, 480, 8), (848, 480, 8), (100, 70, 5), (9, 9, 3)])
+def test_pyramid_stage(gpu, oracle_mod, w, h, levels):
+    torch, orbfe = gpu
+    img0 = synth.frame(w, h, 11, "uniform")
+    ref = [img0]
+    for _ in range(1, levels):
+        ref.append(oracle_mod.halfsample(ref[-1]))
+    bufs, descs = [], []
+    for l in range(levels):
+        lw, lh = w >> l, h >> l
+        pitch = max(lw, 1) + 3
+        t = torch.full((max(lh, 1), pitch), 0x77, dtype=torch.uint8, device="cuda")
+        if l == 0:
+            t[:, :lw] = dev(torch, img0)
+        bufs.append(t)
+        descs.append((t.data_ptr(), lw, lh, pitch))
+    lv = orbfe.make_levels(descs)
+    orbfe.check(orbfe.lib().orbfe_pyramid_create_levels(lv, levels, stream(torch)))
+    for l in range(1, levels):
+        lw, lh = w >> l, h >> l
+        got = bufs[l].cpu().numpy()
+        np.testing.assert_array_equal(got[:lh, :lw], ref[l])
+        assert (got[:, lw:] == 0x77).all()
+
+
+# ------------------------------------------------------------------ a4 LUT
+@pytest.mark.parametrize("arc", [1, 9, 10, 11, 12, 16])
+def test_lut(gpu, oracle_mod, arc):
+    torch, orbfe = gpu
+    lut = torch.zeros(65536, dtype=torch.uint8, device="cuda")
+    orbfe.check(orbfe.lib().orbfe_fast_calculate_lut(lut.data_ptr(), arc, stream(torch)))
+    np.testing.assert_array_equal(lut.cpu().numpy(), oracle_mod.fast_lut(arc))
+
+
+# ------------------------------------------------------------------ a5 response
+@pytest.mark.parametrize("kind", ["rects", "dense", "uniform", "const"])
+@pytest.mark.parametrize("w,h,arc,thr", [(640, 480, 12, 13.0), (212, 120, 9, 13.0), (53, 30, 12, 7.5)])
+def test_fast_response_stage(gpu, oracle_mod, kind, w, h, arc, thr):
+    torch, orbfe = gpu
+    img = oracle_mod.gaussian_blur_3x3(FRAMES[kind](w, h))
+    lut_np = oracle_mod.fast_lut(arc)
+    ref = oracle_mod.fast_response(img, lut_np, thr)
+    d_img, d_lut = pitched(torch, img, w + 4), dev(torch, lut_np)
+    resp = torch.full((h, w + 8), -3.0, dtype=torch.float32, device="cuda")
+    orbfe.check(orbfe.lib().orbfe_fast_calc_corner_response(
+        w, h, w + 4, d_img.data_ptr(), 3, 3, d_lut.data_ptr(), thr, arc,
+        orbfe.SUM_OF_ABS_DIFF_ON_ARC, w + 8, resp.data_ptr(), stream(torch)))
+    got = resp.cpu().numpy()
+    np.testing.assert_array_equal(bits(got[:, :w]), bits(ref))
+    if kind in ("dense", "uniform"):
+        assert (ref > 0).sum() > 10
+
+
+def _response_pyramid(oracle_mod, img0, levels, arc=12, thr=13.0):
+    lut = oracle_mod.fast_lut(arc)
+    imgs = [oracle_mod.gaussian_blur_3x3(img0)]
+    for _ in range(1, levels):
+        imgs.append(oracle_mod.halfsample(imgs[-1]))
+    return imgs, [oracle_mod.fast_response(i, lut, thr) if min(i.shape) > 0 else
+                  np.zeros(i.shape, np.float32) for i in imgs], lut
+
+
+def _tie_responses(w, h, levels, seed):
+    """Response maps with very many equal maxima to exercise the tie order (Q6)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for l in range(levels):
+        lw, lh = w >> l, h >> l
+        r = np.zeros((lh, lw), np.float32)
+        if lw > 6 and lh > 6:
+            m = rng.random((lh, lw)) < 0.08
+            r[m] = rng.integers(1, 4, size=int(m.sum())).astype(np.float32) * 10
+            r[:3] = 0
+            r[-3:] = 0
+            r[:, :3] = 0
+            r[:, -3:] = 0
+        out.append(r)
+    return out
+
+
+# ------------------------------------------------------------------ a6 grid NMS
+@pytest.mark.parametrize("w,h,levels,src", [(640, 480, 1, "img"), (640, 480, 6, "img"),
+                                            (848, 480, 6, "img"), (640, 480, 6, "ties"),
+                                            (848, 480, 5, "ties"), (100, 70, 4, "ties")])
+def test_grid_nms_stage(gpu, oracle_mod, w, h, levels, src):
+    torch, orbfe = gpu
+    if src == "img":
+        _, resps, _ = _response_pyramid(oracle_mod, synth.frame(w, h, 5, "rects", **synth.DENSE), levels)
+    else:
+        resps = _tie_responses(w, h, levels, 42)
+    rpos, rscore, rlevel = oracle_mod.grid_nms(resps, 32)
+    k = oracle_mod.num_cells(w, h, 32)
+    d_res = [dev(torch, r if r.size else np.zeros((1, 1), np.float32)) for r in resps]
+    descs_i = [(0, w >> l, h >> l, max(w >> l, 1)) for l in range(levels)]
+    descs_r = [(d_res[l].data_ptr(), w >> l, h >> l, max(w >> l, 1) * 4) for l in range(levels)]
+    lv = orbfe.make_levels(descs_i, descs_r)
+    grid = torch.full((4 * k,), -1.0, dtype=torch.float32, device="cuda")
+    base = grid.data_ptr()
+    orbfe.check(orbfe.lib().orbfe_grid_nms(lv, levels, base, base + 8 * k, base + 12 * k, stream(torch)))
+    g = grid.cpu().numpy()
+    np.testing.assert_array_equal(bits(g[2 * k:3 * k]), bits(rscore))
+    np.testing.assert_array_equal(bits(g[:2 * k].reshape(k, 2)), bits(rpos))
+    np.testing.assert_array_equal(g[3 * k:].view(np.int32), rlevel)
+    if src == "ties":
+        assert (rscore > 0).sum() > k // 2
+
+
+# ------------------------------------------------------------------ a7 detect
+def test_detect_stage(gpu, oracle_mod):
+    torch, orbfe = gpu
+    w, h, levels = 640, 480, 5
+    imgs, resps, lut = _response_pyramid(oracle_mod, synth.frame(w, h, 9, "rects", **synth.DENSE), levels)
+    rpos, rscore, rlevel = oracle_mod.grid_nms(resps, 32)
+    k = oracle_mod.num_cells(w, h)
+    d_img = [dev(torch, i) for i in imgs]
+    d_res = [torch.full(i.shape, -1.0, dtype=torch.float32, device="cuda") for i in imgs]
+    lv = orbfe.make_levels([(d_img[l].data_ptr(), w >> l, h >> l, w >> l) for l in range(levels)],
+                           [(d_res[l].data_ptr(), w >> l, h >> l, (w >> l) * 4) for l in range(levels)])
+    d_lut = dev(torch, lut)
+    grid = torch.zeros(4 * k, dtype=torch.float32, device="cuda")
+    b = grid.data_ptr()
+    orbfe.check(orbfe.lib().orbfe_detect(lv, levels, d_lut.data_ptr(), 13.0, b, b + 8 * k, b + 12 * k,
+                                         stream(torch)))
+    g = grid.cpu().numpy()
+    np.testing.assert_array_equal(bits(g[2 * k:3 * k]), bits(rscore))
+    np.testing.assert_array_equal(bits(g[:2 * k].reshape(k, 2)), bits(rpos))
+    np.testing.assert_array_equal(g[3 * k:].view(np.int32), rlevel)
+    for l in range(levels):
+        np.testing.assert_array_equal(bits(d_res[l].cpu().numpy()), bits(resps[l]))
+
+
+# ------------------------------------------------------------------ a8 / a9 / a10
+def _keypoint_positions(w, h, n, seed):
+    rng = np.random.default_rng(seed)
+    pos = np.stack([rng.integers(0, w, n), rng.integers(0, h, n)], 1).astype(np.float32)
+    # corners, borders and the descriptor guard band (17 px) explicitly
+    edge = np.array([[0, 0], [w - 1, h - 1], [3, 3], [w - 4, h - 4], [16, 16], [17, 17],
+                     [w - 17, h - 17], [w - 16, h - 16], [17, h - 17], [w - 17, 17],
+                     [15, 200], [200, 15], [w - 1, 200], [200, h - 1]], np.float32)
+    return np.concatenate([edge, pos])
+
+
+@pytest.mark.parametrize("w,h,kind", [(640, 480, "dense"), (848, 480, "uniform"), (100, 70, "rects")])
+def test_angle_and_orb_stage(gpu, oracle_mod, w, h, kind):
+    torch, orbfe = gpu
+    img = oracle_mod.gaussian_blur_3x3(FRAMES[kind](w, h))
+    pos = _keypoint_positions(w, h, 500, 3)
+    n = pos.shape[0]
+    ref_angle = oracle_mod.compute_fast_angle(pos, None, img)
+    ref_desc, ref_d32 = oracle_mod.calc_orb(ref_angle, pos, img)
+    d_img = pitched(torch, img, w + 7)
+    d_pos = dev(torch, pos)
+    d_angle = torch.full((n,), 9.0, dtype=torch.float32, device="cuda")
+    orbfe.check(orbfe.lib().orbfe_compute_fast_angle(d_angle.data_ptr(), d_pos.data_ptr(),
+                                                     d_img.data_ptr(), w + 7, w, h, n, stream(torch)))
+    np.testing.assert_array_equal(bits(d_angle.cpu().numpy()), bits(ref_angle))
+    d_desc = torch.full((n, 32), 0xEE, dtype=torch.uint8, device="cuda")
+    d_d32 = torch.zeros(n, dtype=torch.int32, device="cuda")
+    orbfe.check(orbfe.lib().orbfe_calc_orb(d_angle.data_ptr(), d_pos.data_ptr(), d_desc.data_ptr(),
+                                           d_d32.data_ptr(), d_img.data_ptr(), w + 7, w, h, n,
+                                           stream(torch)))
+    np.testing.assert_array_equal(d_desc.cpu().numpy(), ref_desc)
+    np.testing.assert_array_equal(d_d32.cpu().numpy().view(np.uint32), ref_d32)
+    assert (ref_desc.sum(1) > 0).sum() > n // 2
+    assert np.unique(bits(ref_angle)).size > n // 2
+
+
+# ------------------------------------------------------------------ a11 matchers
+def _match_inputs(n_prev, n_curr, seed):
+    rng = np.random.default_rng(seed)
+    # few distinct positions and sparse 32-bit words -> many in-window candidates and ties
+    pp = rng.integers(0, 12, (n_prev, 2)).astype(np.float32)
+    pc = rng.integers(0, 12, (n_curr, 2)).astype(np.float32)
+    dp = (rng.integers(0, 2, (n_prev, 32)) * (rng.random((n_prev, 32)) < 0.15)).astype(np.uint32)
+    dc = (rng.integers(0, 2, (n_curr, 32)) * (rng.random((n_curr, 32)) < 0.15)).astype(np.uint32)
+    sh = np.arange(32, dtype=np.uint32)
+    return pp, (dp << sh).sum(1).astype(np.uint32), pc, (dc << sh).sum(1).astype(np.uint32)
+
+
+@pytest.mark.parametrize("n_prev,n_curr", [(0, 10), (10, 0), (1, 1), (31, 33), (32, 32), (33, 31),
+                                           (300, 300), (405, 397), (1000, 70), (70, 1000), (257, 64)])
+def test_match_keypoints_stage(gpu, oracle_mod, n_prev, n_curr):
+    torch, orbfe = gpu
+    pp, dp, pc, dc = _match_inputs(n_prev, n_curr, n_prev * 1000 + n_curr)
+    ref_idx, ref_n = oracle_mod.match_keypoints(pp, dp, pc, dc, 2, 4)
+    mk = lambda a, dt: dev(torch, a.view(dt) if a.size else np.zeros(2, dt))
+    d_pp, d_pc = mk(pp, np.float32), mk(pc, np.float32)
+    d_dp, d_dc = mk(dp, np.int32), mk(dc, np.int32)
+    d_idx = torch.full((max(n_prev, 1),), -5, dtype=torch.int32, device="cuda")
+    d_n = torch.full((1,), -5, dtype=torch.int32, device="cuda")
+    orbfe.check(orbfe.lib().orbfe_match_keypoints(d_pp.data_ptr(), d_dp.data_ptr(), n_prev,
+                                                  d_pc.data_ptr(), d_dc.data_ptr(), n_curr, 2, 4,
+                                                  d_idx.data_ptr(), d_n.data_ptr(), stream(torch)))
+    assert int(d_n.cpu()[0]) == ref_n
+    np.testing.assert_array_equal(d_idx.cpu().numpy()[:n_prev], ref_idx)
+    if min(n_prev, n_curr) >= 300:
+        assert ref_n > 20
+
+
+@pytest.mark.parametrize("na,nb,window,maxd", [(0, 5, -1, 256), (5, 0, -1, 256), (1, 1, -1, 256),
+                                               (405, 405, -1, 256), (2000, 1999, -1, 256),
+                                               (300, 700, 3, 256), (513, 255, -1, 100)])
+def test_match256_stage(gpu, oracle_mod, na, nb, window, maxd):
+    torch, orbfe = gpu
+    da, db = synth.descriptors(max(na, 1), 5)[:na], synth.descriptors(max(nb, 1), 6)[:nb]
+    if nb > 10 and na > 10:
+        db[7] = db[3]            # exact duplicates in B: tie -> lower index
+        da[5] = db[3]
+        da[6] = db[9]
+    rng = np.random.default_rng(na + nb)
+    pa = rng.integers(0, 12, (na, 2)).astype(np.float32)
+    pb = rng.integers(0, 12, (nb, 2)).astype(np.float32)
+    ref_idx, ref_dist = oracle_mod.match256(da, db, pa, pb, window, maxd)
+    z = lambda a, dt: dev(torch, a if a.size else np.zeros((1, 32), dt))
+    d_a, d_b = z(da, np.uint8), z(db, np.uint8)
+    d_pa, d_pb = z(pa, np.float32), z(pb, np.float32)
+    d_idx = torch.full((max(na, 1),), -5, dtype=torch.int32, device="cuda")
+    d_dist = torch.full((max(na, 1),), -5, dtype=torch.int32, device="cuda")
+    orbfe.check(orbfe.lib().orbfe_match256(d_a.data_ptr(), d_pa.data_ptr(), na, d_b.data_ptr(),
+                                           d_pb.data_ptr(), nb, window, maxd, d_idx.data_ptr(),
+                                           d_dist.data_ptr(), stream(torch)))
+    np.testing.assert_array_equal(d_idx.cpu().numpy()[:na], ref_idx)
+    np.testing.assert_array_equal(d_dist.cpu().numpy()[:na], ref_dist)
+    if na > 10 and nb > 10 and window < 0 and maxd == 256:
+        assert ref_idx[5] == 3 and ref_dist[5] == 0
+
+
+# ------------------------------------------------------------------ batch extract
+def _run_extract(torch, orbfe, frames, want_soa=True, **cfg):
+    n, h, w = frames.shape
+    ctx = orbfe.Context(w, h, max_batch=n, **cfg)
+    d_in = dev(torch, frames)
+    rec = torch.zeros(n * ctx.cap * 52, dtype=torch.uint8, device="cuda")
+    cnt = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    K = ctx.K
+    soa_t = None
+    soa = None
+    if want_soa:
+        soa_t = dict(pos=torch.full((n, K, 2), -1.0, device="cuda"), score=torch.full((n, K), -1.0, device="cuda"),
+                     level=torch.full((n, K), -1, dtype=torch.int32, device="cuda"),
+                     angle=torch.full((n, K), -1.0, device="cuda"),
+                     desc=torch.full((n, K, 32), 0xEE, dtype=torch.uint8, device="cuda"),
+                     desc32=torch.full((n, K), -1, dtype=torch.int32, device="cuda"))
+        soa = orbfe.Soa(soa_t["pos"].data_ptr(), soa_t["score"].data_ptr(), soa_t["level"].data_ptr(),
+                        soa_t["angle"].data_ptr(), soa_t["desc"].data_ptr(), soa_t["desc32"].data_ptr())
+    ctx.extract(d_in.data_ptr(), w, w * h, n, rec.data_ptr(), cnt.data_ptr(), soa, stream(torch))
+    torch.cuda.synchronize()
+    records = rec.cpu().numpy().view(orbfe.KEYPOINT_DTYPE).reshape(n, ctx.cap)
+    counts = cnt.cpu().numpy()
+    soa_np = {k: v.cpu().numpy() for k, v in soa_t.items()} if want_soa else None
+    return ctx, records, counts, soa_np
+
+
+def _check_extract(oracle_mod, ctx, frames, records, counts, soa_np, **cfg):
+    n, h, w = frames.shape
+    ocfg = oracle_mod.make_config(w, h, levels=cfg.get("levels", 1), cell=cfg.get("cell", 32),
+                                  fast_threshold=float(cfg.get("fast_threshold", 13)),
+                                  min_arc=cfg.get("min_arc", 12),
+                                  max_features=cfg.get("max_features", 0),
+                                  angle_in_radians=cfg.get("angle_in_radians", 0))
+    total = 0
+    for f in range(n):
+        ref = oracle_mod.extract_frame(frames[f], ocfg, want_pyramid=True)
+        for l in range(ocfg.levels):
+            np.testing.assert_array_equal(ctx.read_level(l, f), ref["pyramid"][l],
+                                          err_msg="pyramid level %d frame %d" % (l, f))
+        assert counts[f] == ref["count"], "frame %d count" % f
+        got = records[f, :counts[f]]
+        assert got.tobytes() == ref["records"].tobytes(), "frame %d records differ" % f
+        if soa_np is not None:
+            np.testing.assert_array_equal(bits(soa_np["score"][f]), bits(ref["score"]))
+            np.testing.assert_array_equal(bits(soa_np["pos"][f]), bits(ref["pos"]))
+            np.testing.assert_array_equal(soa_np["level"][f], ref["level"])
+            np.testing.assert_array_equal(bits(soa_np["angle"][f]), bits(ref["angle"]))
+            np.testing.assert_array_equal(soa_np["desc"][f], ref["desc"])
+            np.testing.assert_array_equal(soa_np["desc32"][f].view(np.uint32), ref["desc32"])
+        total += ref["count"]
+    return total
+
+
+def _mixed_frames(w, h):
+    return np.stack([FRAMES[k](w, h) for k in ("rects", "dense", "uniform", "const", "checker")])
+
+
+@pytest.mark.parametrize("w,h,levels", [(640, 480, 1), (640, 480, 6), (848, 480, 6), (100, 70, 3)])
+def test_extract_reference_mode(gpu, oracle_mod, w, h, levels):
+    """Reference-parity configuration: 32-px cells, FAST-12, t = 13, level-0 description."""
+    torch, orbfe = gpu
+    frames = _mixed_frames(w, h)
+    cfg = dict(levels=levels)
+    ctx, rec, cnt, soa = _run_extract(torch, orbfe, frames, **cfg)
+    total = _check_extract(oracle_mod, ctx, frames, rec, cnt, soa, **cfg)
+    assert cnt[3] == 0, "constant frame must give no keypoints"
+    assert total > 50
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(levels=8, cell=8, min_arc=9, max_features=2000),   # the bench configuration (C2)
+    dict(levels=8, cell=8, min_arc=9, max_features=0),
+    dict(levels=8, cell=16, min_arc=10, max_features=300, fast_threshold=20),
+    dict(levels=7, cell=64, min_arc=12, max_features=0),
+    dict(levels=4, cell=32, min_arc=11, max_features=17, angle_in_radians=1),
+    dict(levels=8, cell=8, min_arc=9, max_features=2000, angle_in_radians=1),
+])
+def test_extract_ext_modes(gpu, oracle_mod, cfg):
+    torch, orbfe = gpu
+    frames = _mixed_frames(640, 480)
+    ctx, rec, cnt, soa = _run_extract(torch, orbfe, frames, **cfg)
+    total = _check_extract(oracle_mod, ctx, frames, rec, cnt, soa, **cfg)
+    assert total > 100
+    if cfg["max_features"]:
+        assert cnt.max() <= cfg["max_features"]
+        if cfg["cell"] == 8:
+            assert cnt[2] == cfg["max_features"], "uniform noise fills the feature budget"
+
+
+def test_extract_unaligned_input_pitch(gpu, oracle_mod):
+    torch, orbfe = gpu
+    w, h = 333, 97
+    img = synth.frame(w, h, 4, "rects", **synth.DENSE)
+    ctx = orbfe.Context(w, h, levels=4, max_batch=1)
+    d_in = pitched(torch, img, w + 1)
+    rec = torch.zeros(ctx.cap * 52, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ctx.extract(d_in.data_ptr(), w + 1, (w + 1) * h, 1, rec.data_ptr(), cnt.data_ptr(), None, stream(torch))
+    ref = oracle_mod.extract_frame(img, oracle_mod.make_config(w, h, levels=4))
+    assert int(cnt.cpu()[0]) == ref["count"] > 0
+    assert rec.cpu().numpy().view(orbfe.KEYPOINT_DTYPE)[:ref["count"]].tobytes() == ref["records"].tobytes()
+
+
+def test_error_paths(gpu):
+    torch, orbfe = gpu
+    with pytest.raises(orbfe.OrbfeError) as e:
+        orbfe.Context(640, 480, cell=24)
+    assert e.value.code == orbfe.ERR_UNSUPPORTED
+    with pytest.raises(orbfe.OrbfeError) as e:
+        orbfe.Context(640, 480, min_arc=8)
+    assert e.value.code == orbfe.ERR_UNSUPPORTED
+    ctx = orbfe.Context(64, 64, max_batch=2)
+    buf = torch.zeros(64 * 64 * 3, dtype=torch.uint8, device="cuda")
+    rec = torch.zeros(3 * ctx.cap * 52, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(3, dtype=torch.int32, device="cuda")
+    with pytest.raises(orbfe.OrbfeError) as e:
+        ctx.extract(buf.data_ptr(), 64, 64 * 64, 3, rec.data_ptr(), cnt.data_ptr(), None, stream(torch))
+    assert e.value.code == orbfe.ERR_CAPACITY
+    assert orbfe.lib().orbfe_gaussian_blur_3x3(0, 0, 0, 0, 0, 0, 0) == orbfe.ERR_INVALID_ARG
+    lv = orbfe.make_levels([(1, 640 >> l, 480 >> l, 640 >> l) for l in range(7)],
+                           [(1, 640 >> l, 480 >> l, (640 >> l) * 4) for l in range(7)])
+    assert orbfe.lib().orbfe_grid_nms(lv, 7, 1, 1, 1, 0) == orbfe.ERR_UNSUPPORTED
+
+
+# ------------------------------------------------------------------ batch matcher
+@pytest.mark.parametrize("mode,window,maxd", [(0, 2, 4), (0, 6, 9), (1, -1, 256), (1, 8, 64)])
+def test_match_batch(gpu, oracle_mod, mode, window, maxd):
+    torch, orbfe = gpu
+    w, h = 640, 480
+    a, b = synth.shifted_pair(w, h, 3, dx=1, dy=0, **synth.DENSE)
+    c = synth.frame(w, h, 8, "rects", **synth.DENSE)
+    frames = np.stack([a, b, c, c])
+    cfg = dict(levels=4, cell=16, min_arc=9)
+    ctx, rec, cnt, _ = _run_extract(torch, orbfe, frames, want_soa=False, **cfg)
+    n = frames.shape[0]
+    d_rec = dev(torch, rec.view(np.uint8).reshape(-1))
+    d_cnt = dev(torch, cnt)
+    d_idx = torch.full(((n - 1) * ctx.cap,), -7, dtype=torch.int32, device="cuda")
+    d_dist = torch.full(((n - 1) * ctx.cap,), -7, dtype=torch.int32, device="cuda")
+    ctx.match_batch(d_rec.data_ptr(), d_cnt.data_ptr(), n, mode, window, maxd, d_idx.data_ptr(),
+                    d_dist.data_ptr(), stream(torch))
+    idx = d_idx.cpu().numpy().reshape(n - 1, ctx.cap)
+    dist = d_dist.cpu().numpy().reshape(n - 1, ctx.cap)
+    n_matched = 0
+    for p in range(n - 1):
+        A, B = rec[p, :cnt[p]], rec[p + 1, :cnt[p + 1]]
+        pa = np.stack([A["x"], A["y"]], 1)
+        pb = np.stack([B["x"], B["y"]], 1)
+        if mode == 0:
+            comp = lambda d: ((d == 1).astype(np.uint32) << np.arange(32, dtype=np.uint32)).sum(1).astype(np.uint32)
+            ref_idx, _ = oracle_mod.match_keypoints(pa, comp(A["desc"]), pb, comp(B["desc"]), window, maxd)
+        else:
+            ref_idx, ref_dist = oracle_mod.match256(A["desc"], B["desc"], pa, pb, window, maxd)
+            np.testing.assert_array_equal(dist[p, :cnt[p]], ref_dist)
+        np.testing.assert_array_equal(idx[p, :cnt[p]], ref_idx)
+        assert (idx[p, cnt[p]:] == -1).all()
+        n_matched += int((ref_idx >= 0).sum())
+    if mode == 1:
+        # frames 2 and 3 are identical: every keypoint matches itself at distance 0
+        np.testing.assert_array_equal(idx[2, :cnt[2]], np.arange(cnt[2]))
+        assert (dist[2, :cnt[2]] == 0).all()
+    assert n_matched > 10
+
+
+# ------------------------------------------------------------------ full-size properties
+def test_full_size_batch_properties(gpu, oracle_mod):
+    """BASELINE configs[1] at bench size (batch 256): size-independent properties.
+    (i) a frame's result does not depend on its position in the batch or on its neighbours;
+    (ii) two runs are bit-identical (no atomics-order dependence); (iii) counts respect the
+    feature budget; (iv) sampled frames equal the oracle."""
+    torch, orbfe = gpu
+    w, h, n = 640, 480, 256
+    base = synth.frames(w, h, 8, 100, "rects", **synth.DENSE)
+    frames = base[np.arange(n) % 8]
+    cfg = dict(levels=8, cell=8, min_arc=9, max_features=2000)
+    ctx, rec, cnt, _ = _run_extract(torch, orbfe, frames, want_soa=False, **cfg)
+    _, rec2, cnt2, _ = _run_extract(torch, orbfe, frames, want_soa=False, **cfg)
+    assert rec.tobytes() == rec2.tobytes() and (cnt == cnt2).all()
+    assert cnt.max() <= 2000 and cnt.min() > 500
+    for f in range(8, n):
+        assert cnt[f] == cnt[f % 8]
+        assert rec[f, :cnt[f]].tobytes() == rec[f % 8, :cnt[f]].tobytes()
+    ocfg = oracle_mod.make_config(w, h, levels=8, cell=8, min_arc=9, max_features=2000)
+    for f in (0, 5):
+        ref = oracle_mod.extract_frame(frames[f], ocfg)
+        assert cnt[f] == ref["count"]
+        assert rec[f, :cnt[f]].tobytes() == ref["records"].tobytes()
