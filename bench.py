@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py -- ORB front-end throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--mode c2|ref]
+
+One "step" = one pass of the hot path over one batch of synthetic frames already resident
+in HBM: orbfe_extract (blur + pyramid -> fused FAST/NMS -> selection -> orientation + rBRIEF
+-> 52-byte records) followed by orbfe_match_batch (frame t-1 -> t inside the batch) and, for
+N > 1, the gather of keypoint records to rank 0 (RCCL).  Frames shard across ranks (weak
+scaling: --batch frames per GPU).  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1]): 640x480 mono, 8-level pyramid, 2000 features/frame.
+In this code base that is: cell 8 (4800 cells, detection on levels 0..3 where the cell is
+>= 1 px), FAST-9 with t = 13, top-2000 by (score desc, cell asc), 256-bit brute-force
+matching.  --mode ref runs the reference-parity configuration instead (cell 32, FAST-12,
+6 levels, <= 300 keypoints/frame, 32-bit windowed matcher) -- a parity case, not the metric.
+
+Only the cpu_baseline leg imports oracle/ (the CPU restatement, timed as a baseline).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "jetracer-orbslam2_amd"))
+
+MODES = {
+    "c2": dict(width=640, height=480, cfg=dict(levels=8, cell=8, min_arc=9, max_features=2000),
+               match=dict(mode=1, window=-1, max_distance=256),
+               workload="640x480 mono, 8-level pyramid, 2000 features/frame (cell 8, FAST-9 t=13, "
+                        "top-2000), 256-bit brute-force match t-1->t"),
+    "ref": dict(width=640, height=480, cfg=dict(levels=6, cell=32, min_arc=12, max_features=0),
+                match=dict(mode=0, window=2, max_distance=4),
+                workload="640x480 mono, reference-parity mode (6 levels, cell 32, FAST-12 t=13, "
+                         "<=300 keypoints), 32-bit windowed match t-1->t"),
+}
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes(width, height, levels, detect_levels, cells, k_out):
+    """B_frame = P0 + 2 * sum(P_l) + 52 * K_out, and its per-kernel split."""
+    p = [(width >> l) * (height >> l) for l in range(levels)]
+    pyramid = p[0] + sum(p)                       # read input, write every level once
+    detect = sum(p[:detect_levels]) + 4 * cells   # read detect levels once, write cell keys
+    describe = 52 * k_out                         # write records (patch gathers hit L2/MALL)
+    frame = p[0] + 2 * sum(p) + 52 * k_out
+    return dict(frame=frame, pyramid=pyramid, detect=detect, describe=describe)
+
+
+def cpu_baseline(frames, mode, seconds=12.0):
+    """Oracle (CPU port of the reference semantics) timed on this host: extract + match."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+    from concurrent.futures import ThreadPoolExecutor
+    m = MODES[mode]
+    ocfg = oracle.make_config(m["width"], m["height"], **m["cfg"])
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))  # a 1-GPU box has a 16-CPU share
+
+    def comp(d):
+        return ((d == 1).astype(np.uint32) << np.arange(32, dtype=np.uint32)).sum(1).astype(np.uint32)
+
+    def extract(i):
+        return oracle.extract_frame(frames[i % len(frames)], ocfg)["records"]
+
+    def match(pair):
+        a, b = pair
+        pa, pb = np.stack([a["x"], a["y"]], 1), np.stack([b["x"], b["y"]], 1)
+        if m["match"]["mode"] == 1:
+            oracle.match256(a["desc"], b["desc"], pa, pb, m["match"]["window"], m["match"]["max_distance"])
+        else:
+            oracle.match_keypoints(pa, comp(a["desc"]), pb, comp(b["desc"]), m["match"]["window"],
+                                   m["match"]["max_distance"])
+
+    # time-bounded: chunks of `cores` frames (extract, then match consecutive pairs) until the
+    # budget is spent, so the sample stays ~`seconds` whatever the host's real CPU share is
+    recs_prev, n_frames, n_pairs, kp = None, 0, 0, 0
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:  # ctypes releases the GIL inside the oracle
+        while time.perf_counter() - t0 < seconds:
+            recs = list(ex.map(extract, range(n_frames, n_frames + cores)))
+            chain = ([recs_prev] if recs_prev is not None else []) + recs
+            list(ex.map(match, zip(chain[:-1], chain[1:])))
+            n_pairs += len(chain) - 1
+            n_frames += len(recs)
+            kp += sum(len(r) for r in recs)
+            recs_prev = recs[-1]
+    dt = time.perf_counter() - t0
+    return dict(value=kp / dt, unit="keypoints/s", cores=cores, kind="port",
+                sample="%d frames extracted + %d frame pairs matched by the CPU oracle on %d threads "
+                       "in %.1f s" % (n_frames, n_pairs, cores, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--mode", choices=sorted(MODES), default="c2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stage-iters", type=int, default=10)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import orbfe
+    from orbfe import synth
+    from orbfe.dist import gather_keypoints
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    m = MODES[args.mode]
+    w, h, B = m["width"], m["height"], args.batch
+    ctx = orbfe.Context(w, h, max_batch=B, device=local_rank, **m["cfg"])
+    # synthetic data: 16 distinct corner-rich scenes per rank, repeated to fill the batch
+    n_distinct = min(16, B)
+    base = synth.frames(w, h, n_distinct, first_index=1000 * rank, kind="rects", **synth.DENSE)
+    frames = torch.from_numpy(base).to(dev)[torch.arange(B, device=dev) % n_distinct].contiguous()
+    rec = torch.zeros(B * ctx.cap * 52, dtype=torch.uint8, device=dev)
+    cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+    idx = torch.zeros(max(B - 1, 1) * ctx.cap, dtype=torch.int32, device=dev)
+    dst = torch.zeros(max(B - 1, 1) * ctx.cap, dtype=torch.int32, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    mm = m["match"]
+
+    def step():
+        ctx.extract(frames.data_ptr(), w, w * h, B, rec.data_ptr(), cnt.data_ptr(), None, s)
+        ctx.match_batch(rec.data_ptr(), cnt.data_ptr(), B, mm["mode"], mm["window"], mm["max_distance"],
+                        idx.data_ptr(), dst.data_ptr(), s)
+        if world > 1:
+            gather_keypoints(rec, cnt, dst=0)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    counts = cnt.cpu().numpy().astype(np.int64)
+    kp_local = int(counts.sum())
+    pairs_local = int((counts[:-1] * counts[1:]).sum())
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([kp_local, pairs_local], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        kp_total, pairs_total = int(tot[0].item()), int(tot[1].item())
+    else:
+        kp_total, pairs_total = kp_local, pairs_local
+
+    # ---- per-stage device time, HIP events on the stream the kernels run on ----------
+    def timed(fn, iters):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters  # ms
+
+    out = None
+    if rank == 0:
+        it = args.stage_iters
+        ms_pyr = timed(lambda: ctx.build_pyramid(frames.data_ptr(), w, w * h, B, s), it)
+        ms_det = timed(lambda: ctx.detect_batch(B, s), it)
+        ms_desc = timed(lambda: ctx.describe_batch(B, rec.data_ptr(), cnt.data_ptr(), None, s), it)
+        ms_match = timed(lambda: ctx.match_batch(rec.data_ptr(), cnt.data_ptr(), B, mm["mode"], mm["window"],
+                                                 mm["max_distance"], idx.data_ptr(), dst.data_ptr(), s), it)
+        detect_levels = sum(1 for l in range(m["cfg"]["levels"]) if (m["cfg"]["cell"] >> l) > 0
+                            and (w >> l) > 0 and (h >> l) > 0)
+        k_out = kp_local / B
+        ab = algorithmic_bytes(w, h, m["cfg"]["levels"], detect_levels, ctx.K, k_out)
+        stages = {"pyramid": ms_pyr, "detect": ms_det, "describe": ms_desc, "match": ms_match}
+        # the dominant HBM-streaming kernel of the extraction path (match is VALU-bound by
+        # construction: its HBM traffic is negligible)
+        dom = max(("pyramid", "detect", "describe"), key=lambda k: stages[k])
+        dom_kernel = {"pyramid": "blur_batch_kernel+halfsample_batch_kernel",
+                      "detect": "detect_tile_kernel", "describe": "select_kernel+describe_kernel"}[dom]
+        achieved = ab[dom] * B / (stages[dom] * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                traffic = tj.get(args.mode, {}).get(dom)
+            except Exception:
+                traffic = None
+        ms_extract = ms_pyr + ms_det + ms_desc
+        out = {
+            "metric": "ORB keypoints/sec end-to-end (extract + match), 640x480 8-level",
+            "value": kp_total * args.steps / elapsed,
+            "unit": "keypoints/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": m["workload"], "frames_per_gpu_per_step": B,
+                       "frames_per_step": B * world, "keypoints_per_frame": k_out,
+                       "collective": "gather of 52-byte keypoint records to rank 0" if world > 1 else "none"},
+            "frames_per_s": B * world * args.steps / elapsed,
+            "matcher_gpairs_per_s": pairs_local / (ms_match * 1e-3) / 1e9,
+            "matcher_pairs_per_step": pairs_total,
+            "stage_ms": stages,
+            "path_hbm": {"algorithmic_bytes_per_frame": ab["frame"],
+                         "achieved_GBps": ab["frame"] * B / (ms_extract * 1e-3) / 1e9,
+                         "frac_of_8TBps": ab["frame"] * B / (ms_extract * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+            "roofline": {"bound": "hbm", "kernel": dom_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": ab[dom] * B, "avg_launch_ms": stages[dom]},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(base, args.mode)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -86,21 +86,92 @@ halfsample_batch_kernel(uint8_t *__restrict__ pyr, size_t fstride, size_t src_of
 }
 
 // ------------------------------------------------------------------------------------
-// a5 + a6 fused  FAST score + 3x3 NMS + per-cell maximum for one 64x32 tile of one level
-// of one frame.  LDS: pixel tile with a 4-pixel halo (ring radius 3 + NMS radius 1), u16
-// score tile with a 1-pixel halo, one key per cell that intersects the tile.
+// a5 + a6 fused  FAST score + 3x3 NMS + per-cell maximum for one 64x32 tile of one level of
+// one frame.  Most pixels are not corners, so the work is staged to keep the lanes busy:
+//   A  load the pixel tile (4-px halo: ring radius 3 + NMS radius 1) into LDS as dwords
+//   B  compass pre-test on 4 pixels per lane with packed-u16 min/max: a cyclic arc of >= 9
+//      (>= 12) ring pixels covers >= 2 (>= 3) of the 4 compass pixels N,E,S,W, so the 2nd
+//      (3rd) largest of them must be brighter than c + t, or the 2nd (3rd) smallest darker
+//      than c - t.  Survivors are compacted into an LDS queue.  (Pure work-skipping, like
+//      the reference's opposite-pair prechecks, fast.cu:98-124: it rejects no corner.)
+//   C  full 16-pixel ring test on queued candidates only, two ring pixels per packed-u16
+//      op (saturating subtracts give the score terms and the label flags at once); scores
+//      go to a u16 LDS tile; positive scores inside the tile are queued again
+//   D  strict 3x3 maximum test on the positives only; winners atomicMax their nms_key()
+//      into the cell (LDS for cells >= 4 px, global for smaller cells)
 // ------------------------------------------------------------------------------------
-constexpr int kPxW = kTileW + 8, kPxH = kTileH + 8; // 72 x 40
-constexpr int kScW = kTileW + 2, kScH = kTileH + 2; // 66 x 34
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ inline us2 U2(uint32_t v) { return __builtin_bit_cast(us2, v); }
+__device__ inline uint32_t U1(us2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ inline us2 ssub(us2 a, us2 b) { return __builtin_elementwise_sub_sat(a, b); }
+__device__ inline us2 pmin(us2 a, us2 b) { return __builtin_elementwise_min(a, b); }
+__device__ inline us2 pmax(us2 a, us2 b) { return __builtin_elementwise_max(a, b); }
+
+constexpr int kPxW = kTileW + 8, kPxH = kTileH + 8; // 72 x 40 pixel tile
+constexpr int kPxDw = kPxW / 4;                      // 18 dwords per row
+constexpr int kScW = kTileW + 2, kScH = kTileH + 2; // 66 x 34 score tile (1-px halo)
 constexpr int kScPitch = kScW + 2;                   // 68
+constexpr int kMaxLdsCells = (kTileW / 4) * (kTileH / 4);
+
+// candidate flags of 4 horizontally adjacent pixels -> bit i = pixel i may be a corner
+__device__ inline uint32_t compass4(uint32_t C, uint32_t Wd, uint32_t Ed, uint32_t Nd, uint32_t Sd,
+                                    uint32_t t2, bool need3)
+{
+    uint32_t out = 0;
+#pragma unroll
+    for (int h = 0; h < 2; h++) { // h = 0: bytes 0,2 (pixels 0,2); h = 1: bytes 1,3 (pixels 1,3)
+        const uint32_t m = 0x00FF00FFu;
+        const us2 c = U2((C >> (8 * h)) & m), w = U2((Wd >> (8 * h)) & m), e = U2((Ed >> (8 * h)) & m),
+                  n = U2((Nd >> (8 * h)) & m), s = U2((Sd >> (8 * h)) & m);
+        const us2 hi = c + U2(t2), lo = ssub(c, U2(t2));
+        const us2 a = pmax(n, s), b = pmin(n, s), cc = pmax(e, w), d = pmin(e, w);
+        const us2 m1 = pmin(a, cc), m2 = pmax(b, d);
+        const us2 s2 = pmax(m1, m2), s3 = pmin(m1, m2); // 2nd and 3rd largest of the four
+        const us2 bv = need3 ? s3 : s2, dv = need3 ? s2 : s3;
+        const uint32_t f = U1(ssub(bv, hi)) | U1(ssub(lo, dv)); // 16-bit lane != 0 <=> candidate
+        out |= ((f & 0xFFFFu) ? 1u : 0u) << h;
+        out |= ((f >> 16) ? 1u : 0u) << (2 + h);
+    }
+    return out;
+}
+
+// FAST score (0 = not a corner) of the pixel at LDS byte pointer p, two ring pixels per op.
+__device__ inline int fast_score_packed(const uint8_t *p, uint32_t t2, int arc)
+{
+    const uint32_t c = p[0];
+    const us2 c2 = U2(c | (c << 16));
+    const us2 hi = c2 + U2(t2), lo = ssub(c2, U2(t2));
+    const us2 one = U2(0x00010001u), two = U2(0x00020002u);
+    us2 sb = U2(0), sd = U2(0), mb = U2(0), md = U2(0);
+#pragma unroll
+    for (int i = 7; i >= 0; i--) { // pair (ring i, ring i + 8); i descending so bit i = flag i
+        const uint32_t v0 = p[ring_dy(i) * kPxW + ring_dx(i)];
+        const uint32_t v1 = p[ring_dy(i + 8) * kPxW + ring_dx(i + 8)];
+        const us2 v = U2(v0 | (v1 << 16));
+        const us2 ab = ssub(v, hi), ad = ssub(lo, v); // score terms v - (c+t), (c-t) - v, or 0
+        sb += ab;
+        sd += ad;
+        mb = mb * two + pmin(ab, one);
+        md = md * two + pmin(ad, one);
+    }
+    const uint32_t ub = U1(mb), ud = U1(md);
+    const uint32_t bright = (ub & 0xFFu) | ((ub >> 16) << 8), dark = (ud & 0xFFu) | ((ud >> 16) << 8);
+    if (!(orbfe_has_arc(bright, arc) | orbfe_has_arc(dark, arc))) return 0;
+    const uint32_t xb = U1(sb), xd = U1(sd);
+    const int rb = (int)((xb & 0xFFFFu) + (xb >> 16)), rd = (int)((xd & 0xFFFFu) + (xd >> 16));
+    return rb > rd ? rb : rd;
+}
 
 __global__ void __launch_bounds__(256)
 detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr,
                    const TileDesc *__restrict__ tiles, uint32_t *__restrict__ cellkey)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_px[kPxH][kPxW];
-    __shared__ uint16_t s_sc[kScH][kScPitch];
-    __shared__ uint32_t s_key[kTileW * kTileH];
+    __shared__ __attribute__((aligned(16))) uint32_t s_px32[kPxH * kPxDw];
+    __shared__ __attribute__((aligned(16))) uint16_t s_sc[kScH * kScPitch];
+    __shared__ uint16_t s_q1[kScH * kPxW]; // candidates: r * kPxW + px
+    __shared__ uint16_t s_q2[kTileW * kTileH];
+    __shared__ uint32_t s_key[kMaxLdsCells];
+    __shared__ int s_n1, s_n2;
 
     const TileDesc td = tiles[blockIdx.x];
     const int f = blockIdx.y;
@@ -108,48 +179,129 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr,
     const int W = g.lv[l].w, H = g.lv[l].h, P = g.lv[l].pitch;
     const uint8_t *img = pyr + (size_t)f * g.frame_stride + g.lv[l].offset;
     const int x0 = td.tx * kTileW, y0 = td.ty * kTileH;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint8_t *s_px = reinterpret_cast<const uint8_t *>(s_px32);
 
-    // pixel tile, as dwords (x0 - 4 is dword aligned; rows are 64-byte aligned)
-    for (int i = tid; i < kPxH * (kPxW / 4); i += 256) {
-        const int r = i / (kPxW / 4), q = i % (kPxW / 4);
+    // ---- A: pixel tile as dwords (x0 - 4 is dword aligned; rows are 64-byte aligned)
+    for (int i = tid; i < kPxH * kPxDw; i += 256) {
+        const int r = i / kPxDw, q = i - r * kPxDw;
         const int gy = y0 - 4 + r, gx = x0 - 4 + 4 * q;
         uint32_t v = 0;
         if (gy >= 0 && gy < H && gx >= 0 && gx < P)
             v = *reinterpret_cast<const uint32_t *>(img + (size_t)gy * P + gx);
-        reinterpret_cast<uint32_t *>(&s_px[r][0])[q] = v;
+        s_px32[i] = v;
     }
+    for (int i = tid; i < kScH * kScPitch / 2; i += 256) reinterpret_cast<uint32_t *>(s_sc)[i] = 0u;
     const int c = g.cell >> l;
+    const bool lds_cells = c >= 4;
     const int ncx = kTileW / c > 0 ? kTileW / c : 1, ncy = kTileH / c > 0 ? kTileH / c : 1;
-    for (int i = tid; i < ncx * ncy; i += 256) s_key[i] = 0u;
-    __syncthreads();
-
-    // scores for the tile and its 1-pixel halo
-    for (int i = tid; i < kScH * kScW; i += 256) {
-        const int ry = i / kScW - 1, rx = i % kScW - 1;
-        const int x = x0 + rx, y = y0 + ry;
-        int sc = 0;
-        if (x >= 3 && y >= 3 && x < W - 3 && y < H - 3)
-            sc = fast_score_int(&s_px[ry + 4][rx + 4], kPxW, g.threshold, g.arc);
-        s_sc[ry + 1][rx + 1] = (uint16_t)sc;
+    if (lds_cells)
+        for (int i = tid; i < ncx * ncy; i += 256) s_key[i] = 0u;
+    if (tid == 0) {
+        s_n1 = 0;
+        s_n2 = 0;
     }
     __syncthreads();
 
-    // strict 3x3 maximum, then the cell's maximum key
-    for (int i = tid; i < kTileW * kTileH; i += 256) {
-        const int ry = i / kTileW, rx = i % kTileW;
-        const uint16_t *q = &s_sc[ry + 1][rx + 1];
+    // ---- B: compass pre-test, 4 pixels per lane; score-tile row r <-> image y0 - 1 + r,
+    //         pixel-tile column px <-> image x0 - 4 + px
+    const uint32_t t2 = (uint32_t)g.threshold * 0x00010001u;
+    const bool need3 = g.arc >= 12;
+    for (int task0 = 0; task0 < kScH * kPxDw; task0 += 256) {
+        const int task = task0 + tid;
+        uint32_t flags = 0;
+        int r = 0, q = 0;
+        if (task < kScH * kPxDw) {
+            r = task / kPxDw;
+            q = task - r * kPxDw;
+            const int y = y0 - 1 + r;
+            // valid pixels: 3 <= x < W - 3 and inside the score tile (px 3 .. 68)
+            const int xb = x0 - 4 + 4 * q;
+            int lo_i = 3 - xb, hi_i = W - 3 - xb; // pixel i valid iff lo_i <= i < hi_i
+            if (q == 0) lo_i = lo_i > 3 ? lo_i : 3;
+            if (q == kPxDw - 1) hi_i = hi_i < 1 ? hi_i : 1;
+            lo_i = lo_i < 0 ? 0 : (lo_i > 4 ? 4 : lo_i);
+            hi_i = hi_i < 0 ? 0 : (hi_i > 4 ? 4 : hi_i);
+            uint32_t valid = (y >= 3 && y < H - 3 && hi_i > lo_i) ? (((1u << hi_i) - 1u) & ~((1u << lo_i) - 1u)) : 0u;
+            if (valid) {
+                const uint32_t *row = s_px32 + (r + 3) * kPxDw;
+                const uint32_t C = row[q];
+                const uint32_t L = q > 0 ? row[q - 1] : 0u, Rr = q < kPxDw - 1 ? row[q + 1] : 0u;
+                const uint32_t Nd = row[q - 3 * kPxDw], Sd = row[q + 3 * kPxDw];
+                const uint32_t Wd = __builtin_amdgcn_alignbyte(C, L, 1);  // bytes x-3 of the 4 pixels
+                const uint32_t Ed = __builtin_amdgcn_alignbyte(Rr, C, 3); // bytes x+3
+                flags = compass4(C, Wd, Ed, Nd, Sd, t2, need3) & valid;
+            }
+        }
+        // wave-level compaction: inclusive scan of the per-lane candidate counts
+        const int cnt = __popc(flags);
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        const int total = __shfl(incl, 63);
+        if (total) {
+            int base = 0;
+            if (lane == 63) base = atomicAdd(&s_n1, total);
+            base = __shfl(base, 63);
+            int slot = base + incl - cnt;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (flags >> i & 1u) s_q1[slot++] = (uint16_t)(r * kPxW + 4 * q + i);
+        }
+    }
+    __syncthreads();
+
+    // ---- C: full ring test on the candidates
+    const int n1 = s_n1;
+    for (int i0 = 0; i0 < n1; i0 += 256) {
+        const int i = i0 + tid;
+        bool pos = false;
+        int e = 0;
+        if (i < n1) {
+            e = s_q1[i];
+            const int r = e / kPxW, px = e - r * kPxW;
+            const int sc = fast_score_packed(s_px + (r + 3) * kPxW + px, t2, g.arc);
+            if (sc) {
+                s_sc[r * kScPitch + px - 3] = (uint16_t)sc;
+                pos = r >= 1 && r <= kTileH && px >= 4 && px < 4 + kTileW;
+            }
+        }
+        const uint64_t m = __ballot(pos);
+        if (m) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_n2, (int)__popcll(m));
+            base = __shfl(base, 0);
+            if (pos) s_q2[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)e;
+        }
+    }
+    __syncthreads();
+
+    // ---- D: strict 3x3 maximum on the positives, then the cell's maximum key
+    const int n2 = s_n2;
+    for (int i = tid; i < n2; i += 256) {
+        const int e = s_q2[i];
+        const int r = e / kPxW, px = e - r * kPxW;
+        const uint16_t *q = &s_sc[r * kScPitch + px - 3];
         const int v = q[0];
-        if (v == 0) continue;
         const bool is_max = v > q[-kScPitch] && v > q[-kScPitch + 1] && v > q[1] &&
                             v > q[kScPitch + 1] && v > q[kScPitch] && v > q[kScPitch - 1] &&
                             v > q[-1] && v > q[-kScPitch - 1];
         if (!is_max) continue;
+        const int rx = px - 4, ry = r - 1;
         const uint32_t key = nms_key(v, l, x0 + rx, y0 + ry, g.cell);
-        atomicMax(&s_key[(ry / c) * ncx + (rx / c)], key);
+        if (lds_cells) {
+            atomicMax(&s_key[(ry / c) * ncx + (rx / c)], key);
+        } else {
+            const int cx = (x0 + rx) / c, cy = (y0 + ry) / c;
+            if (cx < g.cells_x && cy < g.cells_y)
+                atomicMax(&cellkey[(size_t)f * g.K + cy * g.cells_x + cx], key);
+        }
     }
+    if (!lds_cells) return;
     __syncthreads();
-
     for (int i = tid; i < ncx * ncy; i += 256) {
         const uint32_t key = s_key[i];
         if (key == 0u) continue;
@@ -272,13 +424,22 @@ select_kernel(DeviceGeom g, const uint32_t *__restrict__ cellkey, int32_t *__res
 // a8 + a9 + a10 fused: one wave per selected keypoint -> one 52-byte record (+ SoA view).
 // Orientation and descriptor sample the level-0 image only (Q10).
 // ------------------------------------------------------------------------------------
+// The patch a keypoint needs (radius R: 15 for the moments disc and the reference-mode
+// descriptor, 19 once the descriptor really rotates) is staged in LDS by the wave with
+// independent, row-contiguous dword loads (one memory latency instead of ~20 dependent byte
+// gathers); moments and the 512 descriptor samples then read LDS bytes.
+template <int R>
 __global__ void __launch_bounds__(256)
 describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32_t *__restrict__ cellkey,
                 const int32_t *__restrict__ sel, const int32_t *__restrict__ selcount,
                 orbfe_keypoint *__restrict__ records, orbfe_soa soa)
 {
-    const int lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    constexpr int kRows = 2 * R + 1;
+    constexpr int kDw = (2 * R + 3) / 4 + 1; // dwords per patch row incl. alignment slack
+    __shared__ uint32_t s_patch[4][kRows * kDw];
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int slot = blockIdx.x * 4 + wv;
     const int f = blockIdx.y;
     if (slot >= selcount[f]) return; // whole wave
     const int cell = sel[(size_t)f * g.cap + slot];
@@ -288,13 +449,31 @@ describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32_t *_
     const uint8_t *img = pyr + (size_t)f * g.frame_stride + g.lv[0].offset;
     const int P = g.lv[0].pitch;
 
+    const int oy = y - R;
+    const int ax = (x - R) & ~3; // x >= 3, R <= 19: may be negative, still a multiple of 4
+    uint32_t *sp = s_patch[wv];
+#pragma unroll
+    for (int i0 = 0; i0 < kRows * kDw; i0 += 64) {
+        const int i = i0 + lane;
+        const int r = i / kDw, q = i - r * kDw;
+        const int gy = oy + r, gx = ax + 4 * q;
+        uint32_t v = 0;
+        if (i < kRows * kDw && gy >= 0 && gy < g.H && gx >= 0 && gx < P)
+            v = *reinterpret_cast<const uint32_t *>(img + (size_t)gy * P + gx);
+        if (i < kRows * kDw) sp[i] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const LdsPatch px{reinterpret_cast<const uint8_t *>(sp), kDw * 4, oy, ax};
+
     int m10, m01;
-    patch_moments(img, P, g.W, g.H, x, y, lane, &m10, &m01);
+    patch_moments(px, g.W, g.H, x, y, lane, &m10, &m01);
     const float angle = orbfe_atan2f((float)m01, (float)m10);
 
     uint64_t d[4] = {0, 0, 0, 0};
     if (!orb_border_zero(x, y, g.W, g.H, g.angle_in_radians))
-        orb_describe(img, P, x, y, angle, g.angle_in_radians, lane, d);
+        orb_describe(px, x, y, angle, g.angle_in_radians, lane, d);
 
     uint32_t *rec = reinterpret_cast<uint32_t *>(records + (size_t)f * g.cap + slot);
     if (lane < 8) rec[5 + lane] = (uint32_t)(d[lane >> 1] >> (32 * (lane & 1)));
@@ -384,19 +563,22 @@ match_batch_ref_kernel(const orbfe_keypoint *__restrict__ records, const int32_t
     }
 }
 
+// 256-bit brute force.  Thread = one query of frame p (8 dwords in VGPRs).  The candidates of
+// frame p + 1 are wave-uniform, so they are read with scalar loads (s_load_dwordx8 through the
+// scalar cache) and enter v_xor as SGPR operands: no LDS, no per-lane loads in the loop.
+// Popcounts chain through v_bcnt_u32_b32's accumulate operand.  The running minimum is one
+// v_min_u32 on the packed key (dist << 16 | j): its minimum is the lexicographic (dist, j) one.
+template <bool WINDOW>
 __global__ void __launch_bounds__(256)
 match_batch_256_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *__restrict__ counts,
                        int cap, int window, int max_dist, int32_t *__restrict__ out_idx,
                        int32_t *__restrict__ out_dist)
 {
-    constexpr int T = 256;
-    __shared__ uint4 s_b[T * 2];
-    __shared__ float2 s_p[T];
     const int p = blockIdx.y;
     const int nA = counts[p], nB = counts[p + 1];
-    const uint32_t *A = reinterpret_cast<const uint32_t *>(records + (size_t)p * cap);
-    const uint32_t *B = reinterpret_cast<const uint32_t *>(records + (size_t)(p + 1) * cap);
     const int i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t *__restrict__ A = reinterpret_cast<const uint32_t *>(records + (size_t)p * cap);
+    const uint32_t *__restrict__ B = reinterpret_cast<const uint32_t *>(records + (size_t)(p + 1) * cap);
     const bool live = i < nA;
     uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float ax = 0.f, ay = 0.f;
@@ -408,35 +590,34 @@ match_batch_256_kernel(const orbfe_keypoint *__restrict__ records, const int32_t
         for (int j = 0; j < 8; j++) a[j] = r[5 + j];
     }
     const float win = (float)window;
-    int best = 1 << 30, best_j = -1;
-    for (int base = 0; base < nB; base += T) {
-        const int m = min(T, nB - base);
-        __syncthreads();
-        uint32_t *sb = reinterpret_cast<uint32_t *>(s_b);
-        for (int t = threadIdx.x; t < 8 * m; t += 256) sb[t] = B[13 * (size_t)(base + (t >> 3)) + 5 + (t & 7)];
-        for (int t = threadIdx.x; t < m; t += 256)
-            s_p[t] = make_float2(__uint_as_float(B[13 * (size_t)(base + t)]),
-                                 __uint_as_float(B[13 * (size_t)(base + t) + 1]));
-        __syncthreads();
-        for (int j = 0; j < m; j++) {
-            const uint4 b0 = s_b[2 * j], b1 = s_b[2 * j + 1];
-            int dist = __popc(a[0] ^ b0.x) + __popc(a[1] ^ b0.y) + __popc(a[2] ^ b0.z) +
-                       __popc(a[3] ^ b0.w) + __popc(a[4] ^ b1.x) + __popc(a[5] ^ b1.y) +
-                       __popc(a[6] ^ b1.z) + __popc(a[7] ^ b1.w);
-            if (window >= 0) {
-                const float2 pb = s_p[j];
-                if (fabsf(ax - pb.x) > win || fabsf(ay - pb.y) > win) dist = 1 << 30;
+    uint32_t best = 0xFFFFFFFFu;
+    // whole waves beyond nA have nothing to do (the loop below has no barrier)
+    const bool wave_live = __builtin_amdgcn_readfirstlane((int)(__ballot(live) != 0ull)) != 0;
+    if (wave_live) {
+#pragma unroll 4
+        for (int j = 0; j < nB; j++) {
+            const uint32_t *__restrict__ rb = B + 13 * (size_t)j; // wave-uniform address
+            uint32_t dist = __popc(a[0] ^ rb[5]);
+            dist += __popc(a[1] ^ rb[6]);
+            dist += __popc(a[2] ^ rb[7]);
+            dist += __popc(a[3] ^ rb[8]);
+            dist += __popc(a[4] ^ rb[9]);
+            dist += __popc(a[5] ^ rb[10]);
+            dist += __popc(a[6] ^ rb[11]);
+            dist += __popc(a[7] ^ rb[12]);
+            uint32_t key = (dist << 16) | (uint32_t)j;
+            if (WINDOW) {
+                const float bx = __uint_as_float(rb[0]), by = __uint_as_float(rb[1]);
+                if (fabsf(ax - bx) > win || fabsf(ay - by) > win) key = 0xFFFFFFFFu;
             }
-            if (dist < best) {
-                best = dist;
-                best_j = base + j;
-            }
+            best = key < best ? key : best;
         }
     }
     if (i < cap) {
-        const bool ok = live && best_j >= 0 && best <= max_dist;
-        out_idx[(size_t)p * cap + i] = ok ? best_j : -1;
-        if (out_dist) out_dist[(size_t)p * cap + i] = ok ? best : -1;
+        const int bd = (int)(best >> 16), bj = (int)(best & 0xFFFFu);
+        const bool ok = live && best != 0xFFFFFFFFu && bd <= max_dist;
+        out_idx[(size_t)p * cap + i] = ok ? bj : -1;
+        if (out_dist) out_dist[(size_t)p * cap + i] = ok ? bd : -1;
     }
 }
 
@@ -652,8 +833,12 @@ int orbfe_describe_batch(orbfe_ctx *ctx, int n_frames, orbfe_keypoint *d_records
     ORBFE_HIP_TRY(ctx->err, hipSetDevice(ctx->cfg.device));
     hipLaunchKernelGGL(select_kernel, dim3(n_frames), dim3(256), 0, S(stream), g, ctx->d_cellkey, ctx->d_sel,
                        ctx->d_selcount, d_counts, so);
-    hipLaunchKernelGGL(describe_kernel, dim3((g.cap + 3) / 4, n_frames), dim3(256), 0, S(stream), g, ctx->d_pyr,
-                       ctx->d_cellkey, ctx->d_sel, ctx->d_selcount, d_records, so);
+    if (g.angle_in_radians)
+        hipLaunchKernelGGL(describe_kernel<19>, dim3((g.cap + 3) / 4, n_frames), dim3(256), 0, S(stream), g,
+                           ctx->d_pyr, ctx->d_cellkey, ctx->d_sel, ctx->d_selcount, d_records, so);
+    else
+        hipLaunchKernelGGL(describe_kernel<15>, dim3((g.cap + 3) / 4, n_frames), dim3(256), 0, S(stream), g,
+                           ctx->d_pyr, ctx->d_cellkey, ctx->d_sel, ctx->d_selcount, d_records, so);
     CTX_LAUNCH_CHECK(ctx, "describe_batch");
     return ORBFE_OK;
 }
@@ -679,15 +864,20 @@ int orbfe_match_batch(orbfe_ctx *ctx, const orbfe_keypoint *d_records, const int
         CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "match_batch: null argument");
     if (mode != 0 && mode != 1) CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "match_batch: mode %d", mode);
     if (mode == 0 && window < 0) CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "match_batch: reference mode needs window >= 0");
+    if (mode == 1 && ctx->g.cap > 65535) // packed (dist << 16 | index) key
+        CTX_FAIL(ctx, ORBFE_ERR_UNSUPPORTED, "match_batch: 256-bit mode supports at most 65535 keypoints per frame");
     if (n_frames < 2) return ORBFE_OK;
     const int cap = ctx->g.cap;
     dim3 grid((cap + 255) / 256, n_frames - 1), block(256);
     if (mode == 0)
         hipLaunchKernelGGL(match_batch_ref_kernel, grid, block, 0, S(stream), d_records, d_counts, cap,
                            (float)window, max_distance, d_idx, d_dist);
+    else if (window >= 0)
+        hipLaunchKernelGGL(match_batch_256_kernel<true>, grid, block, 0, S(stream), d_records, d_counts, cap,
+                           window, max_distance, d_idx, d_dist);
     else
-        hipLaunchKernelGGL(match_batch_256_kernel, grid, block, 0, S(stream), d_records, d_counts, cap, window,
-                           max_distance, d_idx, d_dist);
+        hipLaunchKernelGGL(match_batch_256_kernel<false>, grid, block, 0, S(stream), d_records, d_counts, cap,
+                           window, max_distance, d_idx, d_dist);
     CTX_LAUNCH_CHECK(ctx, "match_batch");
     return ORBFE_OK;
 }

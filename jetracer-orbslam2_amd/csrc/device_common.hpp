@@ -5,32 +5,56 @@
 namespace orbfe {
 
 // rBRIEF pattern, 256 rows of (Px, Py, Qx, Qy) (include/orbfe_pattern.h)
-static __constant__ int8_t c_pattern[ORBFE_PATTERN_TESTS * 4] = {ORBFE_PATTERN_VALUES};
+static __constant__ __attribute__((aligned(16))) int8_t c_pattern[ORBFE_PATTERN_TESTS * 4] = {
+    ORBFE_PATTERN_VALUES};
 
 // Orientation patch half-widths, floor(sqrtf(225 - dy*dy) + 0.5) for dy = 0..15
 // (src/cuda/orb.cu:106; dy = 15 gives 0).
 static __constant__ int8_t c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 7, 5, 0};
 
-__device__ inline void patch_moments(const uint8_t *__restrict__ img, int pitch, int w, int h,
-                                     int kx, int ky, int lane, int *m10_out, int *m01_out)
+// Pixel accessors: px(row, col) -> value.  GlobalPx reads the image; LdsPatch reads a patch
+// that one wave staged in LDS (origin = image position of patch byte (0, 0)).
+struct GlobalPx {
+    const uint8_t *img;
+    int pitch;
+    __device__ inline int operator()(int row, int col) const { return img[(size_t)row * pitch + col]; }
+};
+struct LdsPatch {
+    const uint8_t *base; // LDS
+    int pitch_bytes, oy, ox;
+    __device__ inline int operator()(int row, int col) const
+    {
+        return base[(row - oy) * pitch_bytes + (col - ox)];
+    }
+};
+
+// Intensity-centroid moments of the radius-15 disc around (kx, ky) (orb.cu:77-134).  One
+// wave: lane = patch column (0..30) + 32 * half; half 0 sums the centre row and the rows
+// above, half 1 the rows below.  Integer sums (exact), xor-butterfly add reduction.
+template <typename Px>
+__device__ inline void patch_moments(const Px &px, int w, int h, int kx, int ky, int lane,
+                                     int *m10_out, int *m01_out)
 {
     const int col = lane & 31, half = lane >> 5;
     int m10 = 0, m01 = 0;
     const int dx = col - 15;
+    const int adx = dx < 0 ? -dx : dx;
     const int tdx = kx + dx;
     if (col < 31 && tdx > 0 && tdx < w) {
         if (half == 0) {
-            m10 += dx * (int)img[(size_t)ky * pitch + tdx]; // centre row: no row test (:94-102)
+            m10 += dx * px(ky, tdx); // centre row: no row test (:94-102)
+#pragma unroll
             for (int dy = 1; dy < 16; dy++)
-                if (ky - dy > 0 && (dx <= c_umax[dy] && -dx <= c_umax[dy])) {
-                    const int v = img[(size_t)(ky - dy) * pitch + tdx];
+                if (ky - dy > 0 && adx <= c_umax[dy]) {
+                    const int v = px(ky - dy, tdx);
                     m01 -= dy * v;
                     m10 += dx * v;
                 }
         } else {
+#pragma unroll
             for (int dy = 1; dy < 16; dy++)
-                if (ky + dy < h && (dx <= c_umax[dy] && -dx <= c_umax[dy])) {
-                    const int v = img[(size_t)(ky + dy) * pitch + tdx];
+                if (ky + dy < h && adx <= c_umax[dy]) {
+                    const int v = px(ky + dy, tdx);
                     m01 += dy * v;
                     m10 += dx * v;
                 }
@@ -57,8 +81,9 @@ __device__ inline bool orb_border_zero(int lx, int ly, int w, int h, int radians
                    : (lx < 17 || lx > w - 17 || ly < 17 || ly > h - 17);
 }
 
-__device__ inline void orb_describe(const uint8_t *__restrict__ img, int pitch, int lx, int ly,
-                                    float angle, int radians, int lane, uint64_t d[4])
+template <typename Px>
+__device__ inline void orb_describe(const Px &px, int lx, int ly, float angle, int radians, int lane,
+                                    uint64_t d[4])
 {
     ORBFE_NO_CONTRACT
     const float ang = radians ? angle : angle * ORBFE_DEG2RAD_F;
@@ -66,14 +91,14 @@ __device__ inline void orb_describe(const uint8_t *__restrict__ img, int pitch, 
     orbfe_sincosf(ang, &b, &a); // a = cos, b = sin
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const int8_t *pt = c_pattern + 4 * (64 * r + lane);
-        const float px = (float)pt[0], py = (float)pt[1], qx = (float)pt[2], qy = (float)pt[3];
-        const float p1 = px * b, p2 = py * a, p3 = px * a, p4 = py * b;
-        const float q1 = qx * b, q2 = qy * a, q3 = qx * a, q4 = qy * b;
+        const char4 pt = reinterpret_cast<const char4 *>(c_pattern)[64 * r + lane];
+        const float fpx = (float)pt.x, fpy = (float)pt.y, fqx = (float)pt.z, fqy = (float)pt.w;
+        const float p1 = fpx * b, p2 = fpy * a, p3 = fpx * a, p4 = fpy * b;
+        const float q1 = fqx * b, q2 = fqy * a, q3 = fqx * a, q4 = fqy * b;
         const int prow = ly + orbfe_rn_int(p1 + p2), pcol = lx + orbfe_rn_int(p3 - p4);
         const int qrow = ly + orbfe_rn_int(q1 + q2), qcol = lx + orbfe_rn_int(q3 - q4);
-        const int t0 = img[(size_t)prow * pitch + pcol];
-        const int t1 = img[(size_t)qrow * pitch + qcol];
+        const int t0 = px(prow, pcol);
+        const int t1 = px(qrow, qcol);
         d[r] = __ballot(t0 < t1);
     }
 }

@@ -190,7 +190,7 @@ __global__ void fast_angle_kernel(float *__restrict__ d_angle, const float *__re
     // a keypoint the detector produced is >= 3 px inside; an arbitrary caller position may
     // not be: rows outside the image are skipped instead of read (the reference would read
     // out of bounds for the centre row).
-    if (ky >= 0 && ky < h) patch_moments(img, pitch, w, h, kx, ky, lane, &m10, &m01);
+    if (ky >= 0 && ky < h) patch_moments(GlobalPx{img, pitch}, w, h, kx, ky, lane, &m10, &m01);
     if (lane == 0) d_angle[idx] = orbfe_atan2f((float)m01, (float)m10);
 }
 
@@ -210,7 +210,8 @@ __global__ void calc_orb_kernel(const float *__restrict__ d_angle, const float *
     if (idx >= n) return;
     const int lx = (int)(short)d_pos[2 * idx], ly = (int)(short)d_pos[2 * idx + 1];
     uint64_t d[4] = {0, 0, 0, 0};
-    if (!orb_border_zero(lx, ly, w, h, radians)) orb_describe(img, pitch, lx, ly, d_angle[idx], radians, lane, d);
+    if (!orb_border_zero(lx, ly, w, h, radians))
+        orb_describe(GlobalPx{img, pitch}, lx, ly, d_angle[idx], radians, lane, d);
     if (lane < 4) reinterpret_cast<uint64_t *>(d_desc + (size_t)idx * 32)[lane] = d[lane];
     if (lane == 0 && d_desc32) d_desc32[idx] = orb_compress(d);
 }

@@ -20,7 +20,9 @@ def splitmix64(seed, n, start=0):
         return z ^ (z >> np.uint64(31))
 
 
-DENSE = dict(n_rects=2000, min_size=4, max_size=24)  # ~3500 FAST-9 corners at 640x480, cell 8
+# corner-rich scene: 2400-2570 FAST-9 keypoints per 640x480 frame with 8-px cells over 4 levels
+# (about 8 % of the level-0 pixels are FAST-9 corners), i.e. just above a 2000-feature budget
+DENSE = dict(n_rects=800, min_size=6, max_size=32)
 
 
 def frame(width, height, index=0, kind="rects", n_rects=96, min_size=6, max_size=None):
