@@ -563,54 +563,92 @@ match_batch_ref_kernel(const orbfe_keypoint *__restrict__ records, const int32_t
     }
 }
 
-// 256-bit brute force.  Thread = one query of frame p (8 dwords in VGPRs).  The candidates of
-// frame p + 1 are wave-uniform, so they are read with scalar loads (s_load_dwordx8 through the
-// scalar cache) and enter v_xor as SGPR operands: no LDS, no per-lane loads in the loop.
-// Popcounts chain through v_bcnt_u32_b32's accumulate operand.  The running minimum is one
-// v_min_u32 on the packed key (dist << 16 | j): its minimum is the lexicographic (dist, j) one.
+// 256-bit brute force, two kernels.
+// (1) match_gather_kernel repacks the 52-byte records into dense, 32-byte aligned descriptor
+//     rows and float2 positions in context scratch (one coalesced pass, ~90 B per keypoint).
+// (2) match_batch_256_kernel: thread = one query of frame p (8 dwords in VGPRs).  The
+//     candidates of frame p + 1 are wave-uniform, so they are read with scalar loads
+//     (s_load_dwordx8 through the scalar cache) and enter v_xor as SGPR operands: no LDS,
+//     no per-lane loads in the loop.  Popcounts chain through v_bcnt_u32_b32's accumulate
+//     operand.  The running minimum is a v_min_u32 on the packed key (dist << 16 | j): its
+//     minimum is the lexicographic (dist, j) one.
+struct alignas(32) Desc8 {
+    uint32_t w[8];
+};
+
+__global__ void __launch_bounds__(256)
+match_gather_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *__restrict__ counts, int cap,
+                    Desc8 *__restrict__ mdesc, float2 *__restrict__ mpos)
+{
+    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cap) return;
+    const size_t o = (size_t)f * cap + i;
+    Desc8 d = {{0, 0, 0, 0, 0, 0, 0, 0}};
+    float2 p = make_float2(0.f, 0.f);
+    if (i < counts[f]) {
+        const uint32_t *r = reinterpret_cast<const uint32_t *>(records + o);
+        p = make_float2(__uint_as_float(r[0]), __uint_as_float(r[1]));
+#pragma unroll
+        for (int k = 0; k < 8; k++) d.w[k] = r[5 + k];
+    }
+    mdesc[o] = d;
+    mpos[o] = p;
+}
+
 template <bool WINDOW>
 __global__ void __launch_bounds__(256)
-match_batch_256_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *__restrict__ counts,
-                       int cap, int window, int max_dist, int32_t *__restrict__ out_idx,
-                       int32_t *__restrict__ out_dist)
+match_batch_256_kernel(const Desc8 *__restrict__ mdesc, const float2 *__restrict__ mpos,
+                       const int32_t *__restrict__ counts, int cap, int window, int max_dist,
+                       int32_t *__restrict__ out_idx, int32_t *__restrict__ out_dist)
 {
     const int p = blockIdx.y;
     const int nA = counts[p], nB = counts[p + 1];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t *__restrict__ A = reinterpret_cast<const uint32_t *>(records + (size_t)p * cap);
-    const uint32_t *__restrict__ B = reinterpret_cast<const uint32_t *>(records + (size_t)(p + 1) * cap);
+    const Desc8 *__restrict__ Bd = mdesc + (size_t)(p + 1) * cap;
+    const float2 *__restrict__ Bp = mpos + (size_t)(p + 1) * cap;
     const bool live = i < nA;
-    uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    float ax = 0.f, ay = 0.f;
+    Desc8 a = {{0, 0, 0, 0, 0, 0, 0, 0}};
+    float2 pa = make_float2(0.f, 0.f);
     if (live) {
-        const uint32_t *r = A + 13 * (size_t)i;
-        ax = __uint_as_float(r[0]);
-        ay = __uint_as_float(r[1]);
-#pragma unroll
-        for (int j = 0; j < 8; j++) a[j] = r[5 + j];
+        a = mdesc[(size_t)p * cap + i];
+        if (WINDOW) pa = mpos[(size_t)p * cap + i];
     }
     const float win = (float)window;
     uint32_t best = 0xFFFFFFFFu;
-    // whole waves beyond nA have nothing to do (the loop below has no barrier)
+    auto candidate = [&](int j) {
+        const Desc8 b = Bd[j]; // wave-uniform address -> s_load_dwordx8
+        uint32_t dist = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t x = a.w[k] ^ b.w[k];
+            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(dist) : "v"(x));
+        }
+        uint32_t key = (dist << 16) | (uint32_t)j;
+        if (WINDOW) {
+            const float2 pb = Bp[j];
+            if (fabsf(pa.x - pb.x) > win || fabsf(pa.y - pb.y) > win) key = 0xFFFFFFFFu;
+        }
+        return key;
+    };
+    // whole waves beyond nA have nothing to do (the loop has no barrier)
     const bool wave_live = __builtin_amdgcn_readfirstlane((int)(__ballot(live) != 0ull)) != 0;
     if (wave_live) {
-#pragma unroll 4
-        for (int j = 0; j < nB; j++) {
-            const uint32_t *__restrict__ rb = B + 13 * (size_t)j; // wave-uniform address
-            uint32_t dist = __popc(a[0] ^ rb[5]);
-            dist += __popc(a[1] ^ rb[6]);
-            dist += __popc(a[2] ^ rb[7]);
-            dist += __popc(a[3] ^ rb[8]);
-            dist += __popc(a[4] ^ rb[9]);
-            dist += __popc(a[5] ^ rb[10]);
-            dist += __popc(a[6] ^ rb[11]);
-            dist += __popc(a[7] ^ rb[12]);
-            uint32_t key = (dist << 16) | (uint32_t)j;
-            if (WINDOW) {
-                const float bx = __uint_as_float(rb[0]), by = __uint_as_float(rb[1]);
-                if (fabsf(ax - bx) > win || fabsf(ay - by) > win) key = 0xFFFFFFFFu;
-            }
-            best = key < best ? key : best;
+        int j = 0;
+        for (; j + 8 <= nB; j += 8) { // 8 independent candidates per trip: their scalar loads overlap
+            uint32_t k0 = candidate(j), k1 = candidate(j + 1), k2 = candidate(j + 2), k3 = candidate(j + 3);
+            uint32_t k4 = candidate(j + 4), k5 = candidate(j + 5), k6 = candidate(j + 6), k7 = candidate(j + 7);
+            k0 = k0 < k1 ? k0 : k1;
+            k2 = k2 < k3 ? k2 : k3;
+            k4 = k4 < k5 ? k4 : k5;
+            k6 = k6 < k7 ? k6 : k7;
+            k0 = k0 < k2 ? k0 : k2;
+            k4 = k4 < k6 ? k4 : k6;
+            k0 = k0 < k4 ? k0 : k4;
+            best = k0 < best ? k0 : best;
+        }
+        for (; j < nB; j++) {
+            const uint32_t k0 = candidate(j);
+            best = k0 < best ? k0 : best;
         }
     }
     if (i < cap) {
@@ -730,6 +768,8 @@ int orbfe_create(const orbfe_config *cfg, orbfe_ctx **out)
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_cellkey, B * g.K * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_sel, B * g.cap * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_selcount, B * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_mdesc, B * g.cap * 32);
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_mpos, B * g.cap * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_tiles, (tiles.size() + 1) * sizeof(TileDesc));
     if (e == hipSuccess && !tiles.empty())
         e = hipMemcpy(ctx->d_tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice);
@@ -750,6 +790,8 @@ void orbfe_destroy(orbfe_ctx *ctx)
     if (ctx->d_sel) (void)hipFree(ctx->d_sel);
     if (ctx->d_selcount) (void)hipFree(ctx->d_selcount);
     if (ctx->d_tiles) (void)hipFree(ctx->d_tiles);
+    if (ctx->d_mdesc) (void)hipFree(ctx->d_mdesc);
+    if (ctx->d_mpos) (void)hipFree(ctx->d_mpos);
     delete ctx;
 }
 
@@ -872,12 +914,20 @@ int orbfe_match_batch(orbfe_ctx *ctx, const orbfe_keypoint *d_records, const int
     if (mode == 0)
         hipLaunchKernelGGL(match_batch_ref_kernel, grid, block, 0, S(stream), d_records, d_counts, cap,
                            (float)window, max_distance, d_idx, d_dist);
-    else if (window >= 0)
-        hipLaunchKernelGGL(match_batch_256_kernel<true>, grid, block, 0, S(stream), d_records, d_counts, cap,
-                           window, max_distance, d_idx, d_dist);
-    else
-        hipLaunchKernelGGL(match_batch_256_kernel<false>, grid, block, 0, S(stream), d_records, d_counts, cap,
-                           window, max_distance, d_idx, d_dist);
+    else {
+        if (n_frames > ctx->cfg.max_batch)
+            CTX_FAIL(ctx, ORBFE_ERR_CAPACITY, "match_batch: n_frames %d > max_batch %d", n_frames, ctx->cfg.max_batch);
+        Desc8 *md = reinterpret_cast<Desc8 *>(ctx->d_mdesc);
+        float2 *mp = reinterpret_cast<float2 *>(ctx->d_mpos);
+        hipLaunchKernelGGL(match_gather_kernel, dim3((cap + 255) / 256, n_frames), block, 0, S(stream), d_records,
+                           d_counts, cap, md, mp);
+        if (window >= 0)
+            hipLaunchKernelGGL(match_batch_256_kernel<true>, grid, block, 0, S(stream), md, mp, d_counts, cap,
+                               window, max_distance, d_idx, d_dist);
+        else
+            hipLaunchKernelGGL(match_batch_256_kernel<false>, grid, block, 0, S(stream), md, mp, d_counts, cap,
+                               window, max_distance, d_idx, d_dist);
+    }
     CTX_LAUNCH_CHECK(ctx, "match_batch");
     return ORBFE_OK;
 }

@@ -179,6 +179,8 @@ struct orbfe_ctx {
     uint32_t *d_cellkey = nullptr;  // [max_batch][K]
     int32_t *d_sel = nullptr;       // [max_batch][cap] selected cell ids, cell order
     int32_t *d_selcount = nullptr;  // [max_batch]
+    uint8_t *d_mdesc = nullptr;     // [max_batch][cap][32]  matcher scratch: dense descriptors
+    uint8_t *d_mpos = nullptr;      // [max_batch][cap] float2 matcher scratch: positions
     orbfe::TileDesc *d_tiles = nullptr;
     int n_tiles = 0;
     char err[512] = {0};
