@@ -452,43 +452,71 @@ describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32_t *_
     const int oy = y - R;
     const int ax = (x - R) & ~3; // x >= 3, R <= 19: may be negative, still a multiple of 4
     uint32_t *sp = s_patch[wv];
+    {
+        // dword i of the patch = (row i / kDw, column dword i % kDw); i advances by 64 per trip,
+        // so (row, dword) advance by (64 / kDw, 64 % kDw) with one carry: no divisions
+        int r = lane / kDw, q = lane - r * kDw;
 #pragma unroll
-    for (int i0 = 0; i0 < kRows * kDw; i0 += 64) {
-        const int i = i0 + lane;
-        const int r = i / kDw, q = i - r * kDw;
-        const int gy = oy + r, gx = ax + 4 * q;
-        uint32_t v = 0;
-        if (i < kRows * kDw && gy >= 0 && gy < g.H && gx >= 0 && gx < P)
-            v = *reinterpret_cast<const uint32_t *>(img + (size_t)gy * P + gx);
-        if (i < kRows * kDw) sp[i] = v;
+        for (int i0 = 0; i0 < kRows * kDw; i0 += 64) {
+            const int i = i0 + lane;
+            const int gy = oy + r, gx = ax + 4 * q;
+            uint32_t v = 0;
+            // pixels the moments exclude (row <= 0, row >= H, column <= 0, column >= W) are
+            // staged as 0; the descriptor never samples them (17-px guard band)
+            if (i < kRows * kDw && gy > 0 && gy < g.H && gx >= 0 && gx < g.W) {
+                v = *reinterpret_cast<const uint32_t *>(img + (uint32_t)(__mul24(gy, P) + gx));
+                if (gx == 0) v &= 0xFFFFFF00u;
+                const int nv = g.W - gx; // valid bytes in this dword
+                if (nv < 4) v &= (1u << (8 * nv)) - 1u;
+            }
+            if (i < kRows * kDw) sp[i] = v;
+            r += 64 / kDw;
+            q += 64 % kDw;
+            if (q >= kDw) {
+                q -= kDw;
+                r += 1;
+            }
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const LdsPatch px{reinterpret_cast<const uint8_t *>(sp), kDw * 4, oy, ax};
+    const uint8_t *spb = reinterpret_cast<const uint8_t *>(sp);
+    const LdsPatch px{spb, kDw * 4, oy, ax};
 
     int m10, m01;
-    patch_moments(px, g.W, g.H, x, y, lane, &m10, &m01);
+    patch_moments_staged(spb + R * (kDw * 4) + (x - ax), kDw * 4, lane, &m10, &m01);
     const float angle = orbfe_atan2f((float)m01, (float)m10);
 
     uint64_t d[4] = {0, 0, 0, 0};
     if (!orb_border_zero(x, y, g.W, g.H, g.angle_in_radians))
         orb_describe(px, x, y, angle, g.angle_in_radians, lane, d);
 
-    uint32_t *rec = reinterpret_cast<uint32_t *>(records + (size_t)f * g.cap + slot);
-    if (lane < 8) rec[5 + lane] = (uint32_t)(d[lane >> 1] >> (32 * (lane & 1)));
-    if (lane == 8) rec[0] = __float_as_uint((float)x);
-    if (lane == 9) rec[1] = __float_as_uint((float)y);
-    if (lane == 10) rec[2] = __float_as_uint((float)score);
-    if (lane == 11) rec[3] = (uint32_t)level;
-    if (lane == 12) rec[4] = __float_as_uint(angle);
-
-    const size_t o = (size_t)f * g.K + cell;
-    if (soa.d_angle && lane == 13) soa.d_angle[o] = angle;
-    if (soa.d_desc32 && lane == 14) soa.d_desc32[o] = orb_compress(d);
-    if (soa.d_desc && lane < 8)
-        reinterpret_cast<uint32_t *>(soa.d_desc + 32 * o)[lane] =
-            (uint32_t)(d[lane >> 1] >> (32 * (lane & 1)));
+    // every value is wave-uniform: lane 0 stores the 13 dwords of the record
+    if (lane == 0) {
+        uint32_t *rec = reinterpret_cast<uint32_t *>(records + (size_t)f * g.cap + slot);
+        rec[0] = __float_as_uint((float)x);
+        rec[1] = __float_as_uint((float)y);
+        rec[2] = __float_as_uint((float)score);
+        rec[3] = (uint32_t)level;
+        rec[4] = __float_as_uint(angle);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            rec[5 + 2 * k] = (uint32_t)d[k];
+            rec[6 + 2 * k] = (uint32_t)(d[k] >> 32);
+        }
+        const size_t o = (size_t)f * g.K + cell;
+        if (soa.d_angle) soa.d_angle[o] = angle;
+        if (soa.d_desc32) soa.d_desc32[o] = orb_compress(d);
+        if (soa.d_desc) {
+            uint32_t *sd = reinterpret_cast<uint32_t *>(soa.d_desc + 32 * o);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                sd[2 * k] = (uint32_t)d[k];
+                sd[2 * k + 1] = (uint32_t)(d[k] >> 32);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------

@@ -8,6 +8,23 @@ namespace orbfe {
 static __constant__ __attribute__((aligned(16))) int8_t c_pattern[ORBFE_PATTERN_TESTS * 4] = {
     ORBFE_PATTERN_VALUES};
 
+// the same table as floats (one 16-byte load per test instead of four byte->float converts)
+static __constant__ __attribute__((aligned(16))) float c_pattern_f[ORBFE_PATTERN_TESTS * 4] = {
+    ORBFE_PATTERN_VALUES};
+
+// Sum of v over the 64 lanes of the wave, returned in every lane.  DPP adds inside the VALU
+// (row_shr 1,2,4,8, row_bcast 15, row_bcast 31) instead of six LDS-crossbar ds_bpermute hops.
+__device__ inline int wave_sum_i32(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true); // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true); // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true); // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true); // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true); // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true); // row_bcast:31 -> rows 2, 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // Orientation patch half-widths, floor(sqrtf(225 - dy*dy) + 0.5) for dy = 0..15
 // (src/cuda/orb.cu:106; dy = 15 gives 0).
 static __constant__ int8_t c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 7, 5, 0};
@@ -69,6 +86,35 @@ __device__ inline void patch_moments(const Px &px, int w, int h, int kx, int ky,
     *m01_out = m01;
 }
 
+// The same moments from a patch staged in LDS whose EXCLUDED pixels were zeroed at staging
+// time (rows <= 0 or >= h, columns <= 0 or >= w: exactly the tests of orb.cu:98,112,119), so
+// no per-sample test is left: per row one LDS byte read, one select on the disc chord, two
+// adds; m10 takes its dx factor once at the end.  `centre` points at the keypoint's byte.
+__device__ inline void patch_moments_staged(const uint8_t *centre, int pitch_bytes, int lane,
+                                            int *m10_out, int *m01_out)
+{
+    constexpr int kU[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 7, 5, 0};
+    int col = lane & 31;
+    const bool idle = col == 31;
+    col = idle ? 30 : col;
+    const int dx = col - 15, adx = dx < 0 ? -dx : dx;
+    const int step = (lane >> 5) ? pitch_bytes : -pitch_bytes; // half 1 walks down, half 0 up
+    const uint8_t *p = centre + dx;
+    int s = (lane >> 5) ? 0 : (int)p[0]; // centre row belongs to half 0
+    int sy = 0;
+#pragma unroll
+    for (int dy = 1; dy < 16; dy++) {
+        int v = p[dy * step];
+        v = adx <= kU[dy] ? v : 0;
+        s += v;
+        sy += dy * v;
+    }
+    const int m10 = idle ? 0 : dx * s;
+    const int m01 = idle ? 0 : ((lane >> 5) ? sy : -sy);
+    *m10_out = wave_sum_i32(m10);
+    *m01_out = wave_sum_i32(m01);
+}
+
 // ------------------------------------------------------------------------------------
 // rBRIEF (orb.cu:17-75) + 32-bit "compression" (orb.cu:145-169).  One wave per keypoint.
 // In round r (0..3) lane t evaluates pattern test 64 r + t, and the 64-bit __ballot of the
@@ -91,8 +137,8 @@ __device__ inline void orb_describe(const Px &px, int lx, int ly, float angle, i
     orbfe_sincosf(ang, &b, &a); // a = cos, b = sin
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const char4 pt = reinterpret_cast<const char4 *>(c_pattern)[64 * r + lane];
-        const float fpx = (float)pt.x, fpy = (float)pt.y, fqx = (float)pt.z, fqy = (float)pt.w;
+        const float4 pt = reinterpret_cast<const float4 *>(c_pattern_f)[64 * r + lane];
+        const float fpx = pt.x, fpy = pt.y, fqx = pt.z, fqy = pt.w;
         const float p1 = fpx * b, p2 = fpy * a, p3 = fpx * a, p4 = fpy * b;
         const float q1 = fqx * b, q2 = fqy * a, q3 = fqx * a, q4 = fqy * b;
         const int prow = ly + orbfe_rn_int(p1 + p2), pcol = lx + orbfe_rn_int(p3 - p4);
