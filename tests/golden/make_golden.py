@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/oracle_digests.json: SHA-256 of every stage output of the CPU
+oracle on the deterministic synthetic frames (orbfe/synth.py).
+
+The reference (dsvua/jetracer-orbslam2) ships no fixtures and its CUDA path cannot be built
+here, so these are NOT outputs of the reference: they freeze the oracle against regressions
+(an accidental change of the restatement, of the deterministic math, or of a compiler flag
+such as -ffp-contract).  Run from the repo root:  python tests/golden/make_golden.py
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "jetracer-orbslam2_amd"))
+
+CASES = {
+    # name: (width, height, frame kind/kwargs, oracle config)
+    "vga_ref_L1_rects": (640, 480, dict(index=0, kind="rects"), dict(levels=1)),
+    "vga_ref_L6_dense": (640, 480, dict(index=1, kind="rects", n_rects=800, min_size=6, max_size=32), dict(levels=6)),
+    "vga_ref_L6_uniform": (640, 480, dict(index=2, kind="uniform"), dict(levels=6)),
+    "wvga_ref_L6_dense": (848, 480, dict(index=3, kind="rects", n_rects=800, min_size=6, max_size=32), dict(levels=6)),
+    "vga_c2_top2000": (640, 480, dict(index=4, kind="rects", n_rects=800, min_size=6, max_size=32),
+                       dict(levels=8, cell=8, min_arc=9, max_features=2000)),
+    "vga_cell16_arc10_radians": (640, 480, dict(index=5, kind="rects", n_rects=800, min_size=6, max_size=32),
+                                 dict(levels=5, cell=16, min_arc=10, angle_in_radians=1)),
+    "small_64x64": (64, 64, dict(index=6, kind="uniform"), dict(levels=2)),
+}
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def digests(oracle, synth):
+    out = {}
+    for name, (w, h, fk, ck) in CASES.items():
+        img = synth.frame(w, h, **fk)
+        cfg = oracle.make_config(w, h, **ck)
+        r = oracle.extract_frame(img, cfg, want_pyramid=True)
+        d = {"input": sha(img), "count": int(r["count"])}
+        for l, p in enumerate(r["pyramid"]):
+            d["pyramid_%d" % l] = sha(p)
+        for k in ("pos", "score", "level", "angle", "desc", "desc32", "records"):
+            d[k] = sha(r[k])
+        # matcher digests on the frame against a 1-px shifted copy of itself
+        img2 = np.roll(img, 1, axis=1)
+        r2 = oracle.extract_frame(img2, cfg)
+        a, b = r["records"], r2["records"]
+        pa, pb = np.stack([a["x"], a["y"]], 1), np.stack([b["x"], b["y"]], 1)
+        comp = lambda x: ((x == 1).astype(np.uint32) << np.arange(32, dtype=np.uint32)).sum(1).astype(np.uint32)
+        idx, n = oracle.match_keypoints(pa, comp(a["desc"]), pb, comp(b["desc"]), 2, 4)
+        d["match_ref"] = sha(idx)
+        d["match_ref_count"] = int(n)
+        idx, dist = oracle.match256(a["desc"], b["desc"])
+        d["match256_idx"] = sha(idx)
+        d["match256_dist"] = sha(dist)
+        out[name] = d
+    return out
+
+
+if __name__ == "__main__":
+    import oracle
+    from orbfe import synth
+    path = os.path.join(ROOT, "tests", "golden", "oracle_digests.json")
+    json.dump(digests(oracle, synth), open(path, "w"), indent=1, sort_keys=True)
+    print("wrote", path)
