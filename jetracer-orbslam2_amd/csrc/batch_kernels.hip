@@ -21,11 +21,15 @@ __global__ void __launch_bounds__(256)
 blur_batch_kernel(uint8_t *__restrict__ dst, int dst_pitch, size_t dst_fstride,
                   const uint8_t *__restrict__ src, int src_pitch, size_t src_fstride, int w, int h)
 {
-    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    int f, item; // item = (row block, column block), x fastest
+    xcd_remap(gridDim.x, gridDim.y, &f, &item);
+    const int xblocks = (w + 255) / 256;
+    const int by = item / xblocks, bx = item - by * xblocks;
+    const int x0 = (bx * 64 + (threadIdx.x & 63)) * 4;
+    const int y = by * 4 + (threadIdx.x >> 6);
     if (x0 >= w || y >= h) return;
-    dst += (size_t)blockIdx.z * dst_fstride;
-    src += (size_t)blockIdx.z * src_fstride;
+    dst += (size_t)f * dst_fstride;
+    src += (size_t)f * src_fstride;
     uint32_t *o = reinterpret_cast<uint32_t *>(dst + (size_t)y * dst_pitch + x0);
     if (y == 0 || y >= h - 2) {
         *o = 0u;
@@ -69,10 +73,14 @@ __global__ void __launch_bounds__(256)
 halfsample_batch_kernel(uint8_t *__restrict__ pyr, size_t fstride, size_t src_off, int src_pitch,
                         size_t dst_off, int dst_pitch, int dw, int dh)
 {
-    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    int f, item;
+    xcd_remap(gridDim.x, gridDim.y, &f, &item);
+    const int xblocks = (dw + 255) / 256;
+    const int by = item / xblocks, bx = item - by * xblocks;
+    const int x0 = (bx * 64 + (threadIdx.x & 63)) * 4;
+    const int y = by * 4 + (threadIdx.x >> 6);
     if (x0 >= dw || y >= dh) return;
-    uint8_t *base = pyr + (size_t)blockIdx.z * fstride;
+    uint8_t *base = pyr + (size_t)f * fstride;
     const uint8_t *t = base + src_off + (size_t)(2 * y) * src_pitch + 2 * x0;
     const uint2 a = *reinterpret_cast<const uint2 *>(t);
     const uint2 b = *reinterpret_cast<const uint2 *>(t + src_pitch);
@@ -173,8 +181,9 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr,
     __shared__ uint32_t s_key[kMaxLdsCells];
     __shared__ int s_n1, s_n2;
 
-    const TileDesc td = tiles[blockIdx.x];
-    const int f = blockIdx.y;
+    int f, tile_id;
+    xcd_remap(gridDim.x, gridDim.y, &f, &tile_id);
+    const TileDesc td = tiles[tile_id];
     const int l = td.level;
     const int W = g.lv[l].w, H = g.lv[l].h, P = g.lv[l].pitch;
     const uint8_t *img = pyr + (size_t)f * g.frame_stride + g.lv[l].offset;
@@ -439,8 +448,9 @@ describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32_t *_
     __shared__ uint32_t s_patch[4][kRows * kDw];
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int slot = blockIdx.x * 4 + wv;
-    const int f = blockIdx.y;
+    int f, blk;
+    xcd_remap(gridDim.x, gridDim.y, &f, &blk);
+    const int slot = blk * 4 + wv;
     if (slot >= selcount[f]) return; // whole wave
     const int cell = sel[(size_t)f * g.cap + slot];
     const uint32_t key = cellkey[(size_t)f * g.K + cell];
@@ -629,9 +639,10 @@ match_batch_256_kernel(const Desc8 *__restrict__ mdesc, const float2 *__restrict
                        const int32_t *__restrict__ counts, int cap, int window, int max_dist,
                        int32_t *__restrict__ out_idx, int32_t *__restrict__ out_dist)
 {
-    const int p = blockIdx.y;
+    int p, blk;
+    xcd_remap(gridDim.x, gridDim.y, &p, &blk); // all query blocks of a pair share one L2
     const int nA = counts[p], nB = counts[p + 1];
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blk * 256 + threadIdx.x;
     const Desc8 *__restrict__ Bd = mdesc + (size_t)(p + 1) * cap;
     const float2 *__restrict__ Bp = mpos + (size_t)(p + 1) * cap;
     const bool live = i < nA;
@@ -852,7 +863,7 @@ int orbfe_build_pyramid(orbfe_ctx *ctx, const uint8_t *d_gray, size_t pitch, siz
     ORBFE_HIP_TRY(ctx->err, hipSetDevice(ctx->cfg.device));
     const bool vec = (pitch % 4 == 0) && (frame_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_gray) & 3u) == 0);
     {
-        dim3 grid((g.W + 255) / 256, (g.H + 3) / 4, n_frames), block(256);
+        dim3 grid(((g.W + 255) / 256) * ((g.H + 3) / 4), n_frames), block(256);
         if (vec)
             hipLaunchKernelGGL(blur_batch_kernel<true>, grid, block, 0, S(stream), ctx->d_pyr + g.lv[0].offset,
                                g.lv[0].pitch, g.frame_stride, d_gray, (int)pitch, frame_stride, g.W, g.H);
@@ -863,7 +874,7 @@ int orbfe_build_pyramid(orbfe_ctx *ctx, const uint8_t *d_gray, size_t pitch, siz
     for (int l = 1; l < g.L; l++) {
         const int dw = g.lv[l].w, dh = g.lv[l].h;
         if (dw == 0 || dh == 0) break;
-        dim3 grid((dw + 255) / 256, (dh + 3) / 4, n_frames), block(256);
+        dim3 grid(((dw + 255) / 256) * ((dh + 3) / 4), n_frames), block(256);
         hipLaunchKernelGGL(halfsample_batch_kernel, grid, block, 0, S(stream), ctx->d_pyr, g.frame_stride,
                            g.lv[l - 1].offset, g.lv[l - 1].pitch, g.lv[l].offset, g.lv[l].pitch, dw, dh);
     }
