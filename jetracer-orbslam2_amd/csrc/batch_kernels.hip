@@ -94,6 +94,117 @@ halfsample_batch_kernel(uint8_t *__restrict__ pyr, size_t fstride, size_t src_of
 }
 
 // ------------------------------------------------------------------------------------
+// a2 + a3 fused: blur and ALL halvings of one 128x128 level-0 tile in one workgroup (levels
+// 0..7; 2^7 = 128).  The reference's blur has seams every 32 columns (Q2), so a tile needs no
+// horizontal halo at all, only one input row above and below.  Thread = one dword column
+// (4 pixels) x 16 rows with a 3-row sliding window of the horizontal 1-2-1 sums, kept as two
+// 16-bit lanes per dword (even / odd pixels: plain 32-bit adds never carry across lanes
+// because every partial sum is < 2^16).  Left / right neighbour dwords come from the adjacent
+// lanes by DPP (row_shr:1 / row_shl:1; a DPP row is 16 lanes = 64 pixels = two seam segments).
+// Level 1 (2x2 of level 0) and level 2 (2x2 of level 1) are formed in registers as the rows
+// stream by; level 2 goes to LDS and levels 3..7 are a five-step LDS cascade.
+// Requires W % 4 == 0 and a dword-aligned source; otherwise the unfused kernels above run.
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+pyramid_fused_kernel(DeviceGeom g, uint8_t *__restrict__ pyr, const uint8_t *__restrict__ src, int src_pitch,
+                     size_t src_fstride, int tiles_x)
+{
+    __shared__ uint8_t s_l2[32 * 32], s_l3[16 * 16], s_l4[8 * 8], s_l5[4 * 4], s_l6[2 * 2];
+    int f, tile;
+    xcd_remap(gridDim.x, gridDim.y, &f, &tile);
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int tid = threadIdx.x, cx = tid & 31, rg = tid >> 5;
+    const int W = g.W, H = g.H;
+    const int x0 = tx * 128 + 4 * cx;
+    const int ybase = ty * 128 + rg * 16;
+    src += (size_t)f * src_fstride;
+    uint8_t *fb = pyr + (size_t)f * g.frame_stride;
+    const bool col_ok = x0 < W;
+    const uint32_t M = 0x00FF00FFu;
+    const bool seam_l = (cx & 7) == 0, seam_r = (cx & 7) == 7 || x0 + 4 >= W;
+
+    // horizontal 1-2-1 sums of input row yy, as (even pixels, odd pixels) 16-bit lane pairs
+    auto hrow = [&](int yy, uint32_t &hE, uint32_t &hO) {
+        uint32_t v = 0;
+        if (col_ok && yy >= 0 && yy < H) v = *reinterpret_cast<const uint32_t *>(src + (size_t)yy * src_pitch + x0);
+        const uint32_t Ld = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true); // lane - 1
+        const uint32_t Rd = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xF, 0xF, true); // lane + 1
+        const uint32_t Lb = seam_l ? (v & 0xFFu) : (Ld >> 24);
+        const uint32_t Rb = seam_r ? (v >> 24) : (Rd & 0xFFu);
+        const uint32_t E = v & M, O = (v >> 8) & M;
+        hE = ((O << 16) | Lb) + 2u * E + O;
+        hO = E + 2u * O + ((E >> 16) | (Rb << 16));
+    };
+
+    uint32_t aE, aO, bE, bO, cE, cO; // h of rows y-1, y, y+1
+    hrow(ybase - 1, aE, aO);
+    hrow(ybase, bE, bO);
+    uint32_t prev_s = 0;  // level-0 pair sums of the previous (even) row
+    uint32_t prev_l1 = 0; // level-1 row of the previous row pair
+    const bool want1 = g.L > 1, want2 = g.L > 2;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int y = ybase + r;
+        hrow(y + 1, cE, cO);
+        uint32_t oE = ((aE + 2u * bE + cE + 0x00080008u) >> 4) & M;
+        uint32_t oO = ((aO + 2u * bO + cO + 0x00080008u) >> 4) & M;
+        if (y == 0 || y >= H - 2) { // rows the reference never writes (Q1)
+            oE = 0;
+            oO = 0;
+        }
+        if (col_ok && y < H)
+            *reinterpret_cast<uint32_t *>(fb + g.lv[0].offset + (size_t)y * g.lv[0].pitch + x0) = oE | (oO << 8);
+        aE = bE; aO = bO; bE = cE; bO = cO;
+        const uint32_t sum = oE + oO; // (px0 + px1, px2 + px3)
+        if ((r & 1) == 0) {
+            prev_s = sum;
+        } else if (want1) {
+            const uint32_t l1 = ((prev_s + sum) >> 2) & M; // two level-1 pixels
+            if (col_ok && y < H) // both source rows exist <=> level-1 row y/2 exists (y is odd here)
+                *reinterpret_cast<uint16_t *>(fb + g.lv[1].offset + (size_t)(y >> 1) * g.lv[1].pitch + (x0 >> 1)) =
+                    (uint16_t)((l1 & 0xFFu) | ((l1 >> 8) & 0xFF00u));
+            if ((r & 3) == 1) {
+                prev_l1 = l1;
+            } else if (want2) {
+                const uint32_t u = prev_l1 + l1;
+                s_l2[((rg * 16 + r) >> 2) * 32 + cx] = (uint8_t)(((u & 0xFFFFu) + (u >> 16)) >> 2);
+            }
+        }
+    }
+    if (g.L <= 2) return;
+    __syncthreads();
+    // levels 3..7 in LDS; a pixel of level l exists iff x < W >> l and y < H >> l, and every
+    // existing pixel has four existing parents (floor sizes), so garbage never propagates
+    auto quad = [](const uint8_t *p, int pitch, int x, int y) {
+        const uint8_t *q = p + (2 * y) * pitch + 2 * x;
+        return (uint8_t)(((unsigned)q[0] + q[1] + q[pitch] + q[pitch + 1]) >> 2);
+    };
+    if (g.L > 3) s_l3[tid] = quad(s_l2, 32, tid & 15, tid >> 4);
+    __syncthreads();
+    if (g.L > 4 && tid < 64) s_l4[tid] = quad(s_l3, 16, tid & 7, tid >> 3);
+    __syncthreads();
+    if (g.L > 5 && tid < 16) s_l5[tid] = quad(s_l4, 8, tid & 3, tid >> 2);
+    __syncthreads();
+    if (g.L > 6 && tid < 4) s_l6[tid] = quad(s_l5, 4, tid & 1, tid >> 1);
+    __syncthreads();
+    // stores: level l tile is (128 >> l)^2 at (tx, ty) * (128 >> l)
+    auto put = [&](const uint8_t *p, int l, int n) { // n = tile edge at this level
+        for (int i = tid; i < n * n; i += 256) {
+            const int yy = i / n, xx = i - yy * n;
+            const int gx = tx * n + xx, gy = ty * n + yy;
+            if (gx < g.lv[l].w && gy < g.lv[l].h) fb[g.lv[l].offset + (size_t)gy * g.lv[l].pitch + gx] = p[i];
+        }
+    };
+    put(s_l2, 2, 32);
+    if (g.L > 3) put(s_l3, 3, 16);
+    if (g.L > 4) put(s_l4, 4, 8);
+    if (g.L > 5) put(s_l5, 5, 4);
+    if (g.L > 6) put(s_l6, 6, 2);
+    if (g.L > 7 && tid == 0 && tx < g.lv[7].w && ty < g.lv[7].h)
+        fb[g.lv[7].offset + (size_t)ty * g.lv[7].pitch + tx] = quad(s_l6, 2, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------
 // a5 + a6 fused  FAST score + 3x3 NMS + per-cell maximum for one 64x32 tile of one level of
 // one frame.  Most pixels are not corners, so the work is staged to keep the lanes busy:
 //   A  load the pixel tile (4-px halo: ring radius 3 + NMS radius 1) into LDS as dwords
@@ -201,7 +312,7 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr,
         s_px32[i] = v;
     }
     for (int i = tid; i < kScH * kScPitch / 2; i += 256) reinterpret_cast<uint32_t *>(s_sc)[i] = 0u;
-    const int c = g.cell >> l;
+    const int c = g.cell >> l, lc = ilog2(c);
     const bool lds_cells = c >= 4;
     const int ncx = kTileW / c > 0 ? kTileW / c : 1, ncy = kTileH / c > 0 ? kTileH / c : 1;
     if (lds_cells)
@@ -244,17 +355,12 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr,
         }
         // wave-level compaction: inclusive scan of the per-lane candidate counts
         const int cnt = __popc(flags);
-        int incl = cnt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int v = __shfl_up(incl, off);
-            if (lane >= off) incl += v;
-        }
-        const int total = __shfl(incl, 63);
+        const int incl = wave_incl_scan_i32(cnt);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
         if (total) {
             int base = 0;
             if (lane == 63) base = atomicAdd(&s_n1, total);
-            base = __shfl(base, 63);
+            base = __builtin_amdgcn_readlane(base, 63);
             int slot = base + incl - cnt;
 #pragma unroll
             for (int i = 0; i < 4; i++)
@@ -282,7 +388,7 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr,
         if (m) {
             int base = 0;
             if (lane == 0) base = atomicAdd(&s_n2, (int)__popcll(m));
-            base = __shfl(base, 0);
+            base = __builtin_amdgcn_readfirstlane(base);
             if (pos) s_q2[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)e;
         }
     }
@@ -302,9 +408,9 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr,
         const int rx = px - 4, ry = r - 1;
         const uint32_t key = nms_key(v, l, x0 + rx, y0 + ry, g.cell);
         if (lds_cells) {
-            atomicMax(&s_key[(ry / c) * ncx + (rx / c)], key);
+            atomicMax(&s_key[(ry >> lc) * ncx + (rx >> lc)], key);
         } else {
-            const int cx = (x0 + rx) / c, cy = (y0 + ry) / c;
+            const int cx = (x0 + rx) >> lc, cy = (y0 + ry) >> lc;
             if (cx < g.cells_x && cy < g.cells_y)
                 atomicMax(&cellkey[(size_t)f * g.K + cy * g.cells_x + cx], key);
         }
@@ -862,7 +968,13 @@ int orbfe_build_pyramid(orbfe_ctx *ctx, const uint8_t *d_gray, size_t pitch, siz
         CTX_FAIL(ctx, ORBFE_ERR_CAPACITY, "build_pyramid: n_frames %d > max_batch %d", n_frames, ctx->cfg.max_batch);
     ORBFE_HIP_TRY(ctx->err, hipSetDevice(ctx->cfg.device));
     const bool vec = (pitch % 4 == 0) && (frame_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_gray) & 3u) == 0);
-    {
+    int next_level = 1; // first level still to be produced by the unfused halving kernel
+    if (vec && g.W % 4 == 0) {
+        const int tiles_x = (g.W + 127) / 128, tiles_y = (g.H + 127) / 128;
+        hipLaunchKernelGGL(pyramid_fused_kernel, dim3(tiles_x * tiles_y, n_frames), dim3(256), 0, S(stream), g,
+                           ctx->d_pyr, d_gray, (int)pitch, frame_stride, tiles_x);
+        next_level = 8;
+    } else {
         dim3 grid(((g.W + 255) / 256) * ((g.H + 3) / 4), n_frames), block(256);
         if (vec)
             hipLaunchKernelGGL(blur_batch_kernel<true>, grid, block, 0, S(stream), ctx->d_pyr + g.lv[0].offset,
@@ -871,7 +983,7 @@ int orbfe_build_pyramid(orbfe_ctx *ctx, const uint8_t *d_gray, size_t pitch, siz
             hipLaunchKernelGGL(blur_batch_kernel<false>, grid, block, 0, S(stream), ctx->d_pyr + g.lv[0].offset,
                                g.lv[0].pitch, g.frame_stride, d_gray, (int)pitch, frame_stride, g.W, g.H);
     }
-    for (int l = 1; l < g.L; l++) {
+    for (int l = next_level; l < g.L; l++) {
         const int dw = g.lv[l].w, dh = g.lv[l].h;
         if (dw == 0 || dh == 0) break;
         dim3 grid(((dw + 255) / 256) * ((dh + 3) / 4), n_frames), block(256);

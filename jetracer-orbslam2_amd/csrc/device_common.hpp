@@ -25,6 +25,18 @@ __device__ inline int wave_sum_i32(int v)
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// Inclusive prefix sum over the 64 lanes (same DPP ladder); lane 63 holds the total.
+__device__ inline int wave_incl_scan_i32(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);
+    return v;
+}
+
 // Orientation patch half-widths, floor(sqrtf(225 - dy*dy) + 0.5) for dy = 0..15
 // (src/cuda/orb.cu:106; dy = 15 gives 0).
 static __constant__ int8_t c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 7, 5, 0};

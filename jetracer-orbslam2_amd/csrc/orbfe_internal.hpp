@@ -57,18 +57,26 @@ __host__ __device__ inline NmsGeom nms_geom(int cell0, int level)
     return g;
 }
 
+// floor(log2(v)) for v >= 1 (cell sizes and block rows are powers of two)
+__host__ __device__ inline int ilog2(int v)
+{
+    return 31 - __builtin_clz((unsigned)v);
+}
+
 __host__ __device__ inline uint32_t nms_key(int score, int level, int x, int y, int cell0)
 {
-    NmsGeom g = nms_geom(cell0, level);
-    int cx = x / g.c, cy = y / g.c;
-    int tx = x - g.c * cx;
-    int yoff = 3 - g.c * cy;
+    const NmsGeom g = nms_geom(cell0, level);
+    // c and by are powers of two: divisions become shifts / masks
+    const int lc = ilog2(g.c), lby = ilog2(g.by);
+    const int cy = y >> lc;
+    const int tx = x & (g.c - 1);
+    int yoff = 3 - (cy << lc);
     yoff = yoff > 0 ? yoff : 0;
-    int r = y - g.c * cy - yoff;
-    int ty = r % g.by, k = r / g.by;
-    int tid = tx + g.c * ty;
-    uint32_t rank = (((uint32_t)(tid >> 5) * 32u + orbfe_bitrev5((uint32_t)tid & 31u)) << 5) |
-                    (uint32_t)k;
+    const int r = y - (cy << lc) - yoff;
+    const int ty = r & (g.by - 1), k = r >> lby;
+    const int tid = tx + (ty << lc);
+    const uint32_t rank = (((uint32_t)(tid >> 5) * 32u + orbfe_bitrev5((uint32_t)tid & 31u)) << 5) |
+                          (uint32_t)k;
     return ((uint32_t)score << 15) | ((uint32_t)(7 - level) << 12) | (4095u - rank);
 }
 

@@ -344,7 +344,8 @@ def _mixed_frames(w, h):
     return np.stack([FRAMES[k](w, h) for k in ("rects", "dense", "uniform", "const", "checker")])
 
 
-@pytest.mark.parametrize("w,h,levels", [(640, 480, 1), (640, 480, 6), (848, 480, 6), (100, 70, 3)])
+@pytest.mark.parametrize("w,h,levels", [(640, 480, 1), (640, 480, 6), (848, 480, 6), (100, 70, 3),
+                                        (640, 480, 10), (1280, 720, 9), (636, 476, 2), (130, 258, 8)])
 def test_extract_reference_mode(gpu, oracle_mod, w, h, levels):
     """Reference-parity configuration: 32-px cells, FAST-12, t = 13, level-0 description."""
     torch, orbfe = gpu
