@@ -451,7 +451,7 @@ __device__ inline int block_excl_scan(bool flag, int *s_wave, int *total)
 }
 
 __global__ void __launch_bounds__(256)
-select_kernel(DeviceGeom g, const uint32_t *__restrict__ cellkey, int32_t *__restrict__ sel,
+select_kernel(DeviceGeom g, const uint32_t *__restrict__ cellkey, uint4 *__restrict__ sel,
               int32_t *__restrict__ selcount, int32_t *__restrict__ counts_out, orbfe_soa soa)
 {
     __shared__ uint32_t s_hist[4096];
@@ -504,11 +504,11 @@ select_kernel(DeviceGeom g, const uint32_t *__restrict__ cellkey, int32_t *__res
         const bool keep = in && score > 0 && (score > thr || (tie && n_tie + tie_rank < quota));
         int keep_tot;
         const int slot = block_excl_scan(keep, s_wave, &keep_tot);
-        if (keep) sel[(size_t)f * g.cap + n_sel + slot] = k;
-        if (in && (soa.d_pos || soa.d_score || soa.d_level || soa.d_angle || soa.d_desc ||
-                   soa.d_desc32)) {
-            int s, l, x, y;
-            nms_decode(key, k % g.cells_x, k / g.cells_x, g.cell, &s, &l, &x, &y);
+        int s = 0, l = 0, x = 0, y = 0;
+        const bool want_soa = soa.d_pos || soa.d_score || soa.d_level || soa.d_angle || soa.d_desc || soa.d_desc32;
+        if (keep || (in && want_soa)) nms_decode(key, k % g.cells_x, k / g.cells_x, g.cell, &s, &l, &x, &y);
+        if (keep) sel[(size_t)f * g.cap + n_sel + slot] = make_uint4((uint32_t)k, (uint32_t)x | ((uint32_t)y << 16), key, 0u);
+        if (in && want_soa) {
             const size_t o = (size_t)f * g.K + k;
             if (soa.d_pos) {
                 soa.d_pos[2 * o] = (float)x;
@@ -543,93 +543,102 @@ select_kernel(DeviceGeom g, const uint32_t *__restrict__ cellkey, int32_t *__res
 // descriptor, 19 once the descriptor really rotates) is staged in LDS by the wave with
 // independent, row-contiguous dword loads (one memory latency instead of ~20 dependent byte
 // gathers); moments and the 512 descriptor samples then read LDS bytes.
+constexpr int kKpw = 4; // keypoints per wave (consecutive slots = neighbouring cells)
+
 template <int R>
 __global__ void __launch_bounds__(256)
-describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32_t *__restrict__ cellkey,
-                const int32_t *__restrict__ sel, const int32_t *__restrict__ selcount,
-                orbfe_keypoint *__restrict__ records, orbfe_soa soa)
+describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__restrict__ sel,
+                const int32_t *__restrict__ selcount, orbfe_keypoint *__restrict__ records, orbfe_soa soa)
 {
     constexpr int kRows = 2 * R + 1;
     constexpr int kDw = (2 * R + 3) / 4 + 1; // dwords per patch row incl. alignment slack
     __shared__ uint32_t s_patch[4][kRows * kDw];
 
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // scalar: wave-uniform
     int f, blk;
     xcd_remap(gridDim.x, gridDim.y, &f, &blk);
-    const int slot = blk * 4 + wv;
-    if (slot >= selcount[f]) return; // whole wave
-    const int cell = sel[(size_t)f * g.cap + slot];
-    const uint32_t key = cellkey[(size_t)f * g.K + cell];
-    int score, level, x, y;
-    nms_decode(key, cell % g.cells_x, cell / g.cells_x, g.cell, &score, &level, &x, &y);
+    const int n = selcount[f];
     const uint8_t *img = pyr + (size_t)f * g.frame_stride + g.lv[0].offset;
     const int P = g.lv[0].pitch;
-
-    const int oy = y - R;
-    const int ax = (x - R) & ~3; // x >= 3, R <= 19: may be negative, still a multiple of 4
+    const uint4 *fsel = sel + (size_t)f * g.cap;
     uint32_t *sp = s_patch[wv];
-    {
-        // dword i of the patch = (row i / kDw, column dword i % kDw); i advances by 64 per trip,
-        // so (row, dword) advance by (64 / kDw, 64 % kDw) with one carry: no divisions
-        int r = lane / kDw, q = lane - r * kDw;
-#pragma unroll
-        for (int i0 = 0; i0 < kRows * kDw; i0 += 64) {
-            const int i = i0 + lane;
-            const int gy = oy + r, gx = ax + 4 * q;
-            uint32_t v = 0;
-            // pixels the moments exclude (row <= 0, row >= H, column <= 0, column >= W) are
-            // staged as 0; the descriptor never samples them (17-px guard band)
-            if (i < kRows * kDw && gy > 0 && gy < g.H && gx >= 0 && gx < g.W) {
-                v = *reinterpret_cast<const uint32_t *>(img + (uint32_t)(__mul24(gy, P) + gx));
-                if (gx == 0) v &= 0xFFFFFF00u;
-                const int nv = g.W - gx; // valid bytes in this dword
-                if (nv < 4) v &= (1u << (8 * nv)) - 1u;
-            }
-            if (i < kRows * kDw) sp[i] = v;
-            r += 64 / kDw;
-            q += 64 % kDw;
-            if (q >= kDw) {
-                q -= kDw;
-                r += 1;
-            }
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const uint8_t *spb = reinterpret_cast<const uint8_t *>(sp);
-    const LdsPatch px{spb, kDw * 4, oy, ax};
 
-    int m10, m01;
-    patch_moments_staged(spb + R * (kDw * 4) + (x - ax), kDw * 4, lane, &m10, &m01);
-    const float angle = orbfe_atan2f((float)m01, (float)m10);
+    for (int it = 0; it < kKpw; it++) {
+        const int slot = (blk * 4 + wv) * kKpw + it; // wave-uniform
+        if (slot >= n) break;
+        const uint4 sr = fsel[slot]; // uniform address: scalar load
+        const int cell = (int)sr.x, x = (int)(sr.y & 0xFFFFu), y = (int)(sr.y >> 16);
+        const int score = (int)(sr.z >> 15), level = 7 - (int)((sr.z >> 12) & 7u);
 
-    uint64_t d[4] = {0, 0, 0, 0};
-    if (!orb_border_zero(x, y, g.W, g.H, g.angle_in_radians))
-        orb_describe(px, x, y, angle, g.angle_in_radians, lane, d);
-
-    // every value is wave-uniform: lane 0 stores the 13 dwords of the record
-    if (lane == 0) {
-        uint32_t *rec = reinterpret_cast<uint32_t *>(records + (size_t)f * g.cap + slot);
-        rec[0] = __float_as_uint((float)x);
-        rec[1] = __float_as_uint((float)y);
-        rec[2] = __float_as_uint((float)score);
-        rec[3] = (uint32_t)level;
-        rec[4] = __float_as_uint(angle);
+        const int oy = y - R;
+        const int ax = (x - R) & ~3; // x >= 3, R <= 19: may be negative, still a multiple of 4
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // previous keypoint's reads are done
+        __builtin_amdgcn_wave_barrier();
+        {
+            // dword i of the patch = (row i / kDw, column dword i % kDw); i advances by 64 per
+            // trip, so (row, dword) advance by (64 / kDw, 64 % kDw) with one carry: no divisions
+            int r = lane / kDw, q = lane - r * kDw;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            rec[5 + 2 * k] = (uint32_t)d[k];
-            rec[6 + 2 * k] = (uint32_t)(d[k] >> 32);
+            for (int i0 = 0; i0 < kRows * kDw; i0 += 64) {
+                const int i = i0 + lane;
+                const int gy = oy + r, gx = ax + 4 * q;
+                uint32_t v = 0;
+                // pixels the moments exclude (row <= 0, row >= H, column <= 0, column >= W) are
+                // staged as 0; the descriptor never samples them (17-px guard band)
+                if (i < kRows * kDw && gy > 0 && gy < g.H && gx >= 0 && gx < g.W) {
+                    v = *reinterpret_cast<const uint32_t *>(img + (uint32_t)(__mul24(gy, P) + gx));
+                    if (gx == 0) v &= 0xFFFFFF00u;
+                    const int nv = g.W - gx; // valid bytes in this dword
+                    if (nv < 4) v &= (1u << (8 * nv)) - 1u;
+                }
+                if (i < kRows * kDw) sp[i] = v;
+                r += 64 / kDw;
+                q += 64 % kDw;
+                if (q >= kDw) {
+                    q -= kDw;
+                    r += 1;
+                }
+            }
         }
-        const size_t o = (size_t)f * g.K + cell;
-        if (soa.d_angle) soa.d_angle[o] = angle;
-        if (soa.d_desc32) soa.d_desc32[o] = orb_compress(d);
-        if (soa.d_desc) {
-            uint32_t *sd = reinterpret_cast<uint32_t *>(soa.d_desc + 32 * o);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const LdsPatch px{spb, kDw * 4, oy, ax};
+
+        int m10, m01;
+        patch_moments_staged(spb + R * (kDw * 4) + (x - ax), kDw * 4, lane, &m10, &m01);
+        const float angle = orbfe_atan2f((float)m01, (float)m10);
+
+        uint64_t d[4] = {0, 0, 0, 0};
+        if (!orb_border_zero(x, y, g.W, g.H, g.angle_in_radians))
+            orb_describe(px, x, y, angle, g.angle_in_radians, lane, d);
+
+        // every value is wave-uniform: lane 0 stores the 13 dwords of the record
+        if (lane == 0) {
+            uint32_t *rec = reinterpret_cast<uint32_t *>(records + (size_t)f * g.cap + slot);
+            rec[0] = __float_as_uint((float)x);
+            rec[1] = __float_as_uint((float)y);
+            rec[2] = __float_as_uint((float)score);
+            rec[3] = (uint32_t)level;
+            rec[4] = __float_as_uint(angle);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                sd[2 * k] = (uint32_t)d[k];
-                sd[2 * k + 1] = (uint32_t)(d[k] >> 32);
+                rec[5 + 2 * k] = (uint32_t)d[k];
+                rec[6 + 2 * k] = (uint32_t)(d[k] >> 32);
+            }
+            if (soa.d_angle || soa.d_desc32 || soa.d_desc) {
+                const size_t o = (size_t)f * g.K + cell;
+                if (soa.d_angle) soa.d_angle[o] = angle;
+                if (soa.d_desc32) soa.d_desc32[o] = orb_compress(d);
+                if (soa.d_desc) {
+                    uint32_t *sd = reinterpret_cast<uint32_t *>(soa.d_desc + 32 * o);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        sd[2 * k] = (uint32_t)d[k];
+                        sd[2 * k + 1] = (uint32_t)(d[k] >> 32);
+                    }
+                }
             }
         }
     }
@@ -911,7 +920,7 @@ int orbfe_create(const orbfe_config *cfg, orbfe_ctx **out)
     hipError_t e = hipMalloc((void **)&ctx->d_pyr, B * g.frame_stride + 256);
     if (e == hipSuccess) e = hipMemset(ctx->d_pyr, 0, B * g.frame_stride + 256);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_cellkey, B * g.K * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_sel, B * g.cap * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_sel, B * g.cap * sizeof(uint4));
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_selcount, B * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_mdesc, B * g.cap * 32);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_mpos, B * g.cap * 8);
@@ -1027,11 +1036,11 @@ int orbfe_describe_batch(orbfe_ctx *ctx, int n_frames, orbfe_keypoint *d_records
     hipLaunchKernelGGL(select_kernel, dim3(n_frames), dim3(256), 0, S(stream), g, ctx->d_cellkey, ctx->d_sel,
                        ctx->d_selcount, d_counts, so);
     if (g.angle_in_radians)
-        hipLaunchKernelGGL(describe_kernel<19>, dim3((g.cap + 3) / 4, n_frames), dim3(256), 0, S(stream), g,
-                           ctx->d_pyr, ctx->d_cellkey, ctx->d_sel, ctx->d_selcount, d_records, so);
+        hipLaunchKernelGGL(describe_kernel<19>, dim3((g.cap + 4 * kKpw - 1) / (4 * kKpw), n_frames), dim3(256), 0,
+                           S(stream), g, ctx->d_pyr, ctx->d_sel, ctx->d_selcount, d_records, so);
     else
-        hipLaunchKernelGGL(describe_kernel<15>, dim3((g.cap + 3) / 4, n_frames), dim3(256), 0, S(stream), g,
-                           ctx->d_pyr, ctx->d_cellkey, ctx->d_sel, ctx->d_selcount, d_records, so);
+        hipLaunchKernelGGL(describe_kernel<15>, dim3((g.cap + 4 * kKpw - 1) / (4 * kKpw), n_frames), dim3(256), 0,
+                           S(stream), g, ctx->d_pyr, ctx->d_sel, ctx->d_selcount, d_records, so);
     CTX_LAUNCH_CHECK(ctx, "describe_batch");
     return ORBFE_OK;
 }

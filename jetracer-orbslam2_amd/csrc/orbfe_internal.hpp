@@ -96,7 +96,7 @@ __host__ __device__ inline void nms_decode(uint32_t key, int cell_x, int cell_y,
     uint32_t wl = rank >> 5;
     int tid = (int)((wl >> 5) * 32u + orbfe_bitrev5(wl & 31u));
     NmsGeom g = nms_geom(cell0, l);
-    int tx = tid % g.c, ty = tid / g.c;
+    int tx = tid & (g.c - 1), ty = tid >> ilog2(g.c); // c is a power of two
     int yoff = 3 - g.c * cell_y;
     yoff = yoff > 0 ? yoff : 0;
     *level = l;
@@ -185,7 +185,7 @@ struct orbfe_ctx {
     orbfe::DeviceGeom g;
     uint8_t *d_pyr = nullptr;       // [max_batch][frame_stride]
     uint32_t *d_cellkey = nullptr;  // [max_batch][K]
-    int32_t *d_sel = nullptr;       // [max_batch][cap] selected cell ids, cell order
+    uint4 *d_sel = nullptr;         // [max_batch][cap] selected keypoints in cell order: {cell, x | y << 16, key, 0}
     int32_t *d_selcount = nullptr;  // [max_batch]
     uint8_t *d_mdesc = nullptr;     // [max_batch][cap][32]  matcher scratch: dense descriptors
     uint8_t *d_mpos = nullptr;      // [max_batch][cap] float2 matcher scratch: positions
