@@ -109,7 +109,7 @@ def main():
     import torch.distributed as dist
     import orbfe
     from orbfe import synth
-    from orbfe.dist import gather_keypoints
+    from orbfe.dist import gather_keypoints_async
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -130,21 +130,43 @@ def main():
     n_distinct = min(16, B)
     base = synth.frames(w, h, n_distinct, first_index=1000 * rank, kind="rects", **synth.DENSE)
     frames = torch.from_numpy(base).to(dev)[torch.arange(B, device=dev) % n_distinct].contiguous()
-    rec = torch.zeros(B * ctx.cap * 52, dtype=torch.uint8, device=dev)
-    cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+    # records / counts are double-buffered: the gather of step i (RCCL, asynchronous) overlaps
+    # the kernels of step i + 1, which write the other buffer
+    recs = [torch.zeros(B * ctx.cap * 52, dtype=torch.uint8, device=dev) for _ in range(2)]
+    cnts = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
+    rec, cnt = recs[0], cnts[0]
     idx = torch.zeros(max(B - 1, 1) * ctx.cap, dtype=torch.int32, device=dev)
     dst = torch.zeros(max(B - 1, 1) * ctx.cap, dtype=torch.int32, device=dev)
     s = torch.cuda.current_stream().cuda_stream
     mm = m["match"]
+    gather_out = None
+    if world > 1 and rank == 0:
+        gather_out = [(torch.empty((world, B * ctx.cap * 52), dtype=torch.uint8, device=dev),
+                       torch.empty((world, B), dtype=torch.int32, device=dev)) for _ in range(2)]
+    pending = [None, None]
+    step_no = [0]
 
     def step():
-        ctx.extract(frames.data_ptr(), w, w * h, B, rec.data_ptr(), cnt.data_ptr(), None, s)
-        ctx.match_batch(rec.data_ptr(), cnt.data_ptr(), B, mm["mode"], mm["window"], mm["max_distance"],
+        b = step_no[0] & 1
+        step_no[0] += 1
+        if pending[b] is not None:  # the gather that last read this buffer must be done
+            pending[b].wait()
+            pending[b] = None
+        r, c = recs[b], cnts[b]
+        ctx.extract(frames.data_ptr(), w, w * h, B, r.data_ptr(), c.data_ptr(), None, s)
+        ctx.match_batch(r.data_ptr(), c.data_ptr(), B, mm["mode"], mm["window"], mm["max_distance"],
                         idx.data_ptr(), dst.data_ptr(), s)
         if world > 1:
-            gather_keypoints(rec, cnt, dst=0)
+            pending[b] = gather_keypoints_async(r, c, gather_out[b] if gather_out else None, dst=0)
+
+    def drain():
+        for b in (0, 1):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
 
     def sync():
+        drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -229,7 +251,8 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": m["workload"], "frames_per_gpu_per_step": B,
                        "frames_per_step": B * world, "keypoints_per_frame": k_out,
-                       "collective": "gather of 52-byte keypoint records to rank 0" if world > 1 else "none"},
+                       "collective": "async gather of 52-byte keypoint records to rank 0, overlapped with the "
+                                     "next step" if world > 1 else "none"},
             "frames_per_s": B * world * args.steps / elapsed,
             "matcher_gpairs_per_s": pairs_local / (ms_match * 1e-3) / 1e9,
             "matcher_pairs_per_step": pairs_total,

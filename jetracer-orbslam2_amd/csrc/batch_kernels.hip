@@ -728,6 +728,7 @@ match_batch_ref_kernel(const orbfe_keypoint *__restrict__ records, const int32_t
 struct alignas(32) Desc8 {
     uint32_t w[8];
 };
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 
 __global__ void __launch_bounds__(256)
 match_gather_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *__restrict__ counts, int cap,
@@ -769,12 +770,12 @@ match_batch_256_kernel(const Desc8 *__restrict__ mdesc, const float2 *__restrict
     }
     const float win = (float)window;
     uint32_t best = 0xFFFFFFFFu;
-    auto candidate = [&](int j) {
-        const Desc8 b = Bd[j]; // wave-uniform address -> s_load_dwordx8
+    // distance key of one candidate whose descriptor is in SGPRs
+    auto key_of = [&](const u32x8 &b, int j) {
         uint32_t dist = 0;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const uint32_t x = a.w[k] ^ b.w[k];
+            const uint32_t x = a.w[k] ^ b[k];
             asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(dist) : "v"(x));
         }
         uint32_t key = (dist << 16) | (uint32_t)j;
@@ -784,24 +785,57 @@ match_batch_256_kernel(const Desc8 *__restrict__ mdesc, const float2 *__restrict
         }
         return key;
     };
+    auto group_min = [&](const u32x8 (&g)[4], int j) {
+        uint32_t k0 = key_of(g[0], j), k1 = key_of(g[1], j + 1), k2 = key_of(g[2], j + 2), k3 = key_of(g[3], j + 3);
+        k0 = k0 < k1 ? k0 : k1;
+        k2 = k2 < k3 ? k2 : k3;
+        k0 = k0 < k2 ? k0 : k2;
+        best = k0 < best ? k0 : best;
+    };
+    // Hand-made scalar-load pipeline.  SMEM returns out of order, so the only usable wait is
+    // lgkmcnt(0); hipcc places a group's s_loads right before its wait, which exposes the full
+    // scalar-cache latency once per group.  Here the loads of the NEXT group are issued, the
+    // CURRENT group (~100 VALU instructions) is computed, and only then comes the wait.  The
+    // asm operands pin that order: `issue` is ordered before the compute through a.w[0], the
+    // wait after it through `best`, and the loaded tuples only become usable through the wait.
+    // No load is in flight across the loop back edge.
+    auto issue = [&](u32x8 (&g)[4], const Desc8 *src) {
+        asm volatile("s_load_dwordx8 %0, %5, 0x0\n\ts_load_dwordx8 %1, %5, 0x20\n\t"
+                     "s_load_dwordx8 %2, %5, 0x40\n\ts_load_dwordx8 %3, %5, 0x60"
+                     : "=&s"(g[0]), "=&s"(g[1]), "=&s"(g[2]), "=&s"(g[3]), "+v"(a.w[0])
+                     : "s"(src)
+                     : "memory");
+    };
+    auto wait = [&](u32x8 (&g)[4]) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(g[0]), "+s"(g[1]), "+s"(g[2]), "+s"(g[3]), "+v"(best), "+v"(a.w[0]));
+    };
     // whole waves beyond nA have nothing to do (the loop has no barrier)
     const bool wave_live = __builtin_amdgcn_readfirstlane((int)(__ballot(live) != 0ull)) != 0;
     if (wave_live) {
         int j = 0;
-        for (; j + 8 <= nB; j += 8) { // 8 independent candidates per trip: their scalar loads overlap
-            uint32_t k0 = candidate(j), k1 = candidate(j + 1), k2 = candidate(j + 2), k3 = candidate(j + 3);
-            uint32_t k4 = candidate(j + 4), k5 = candidate(j + 5), k6 = candidate(j + 6), k7 = candidate(j + 7);
-            k0 = k0 < k1 ? k0 : k1;
-            k2 = k2 < k3 ? k2 : k3;
-            k4 = k4 < k5 ? k4 : k5;
-            k6 = k6 < k7 ? k6 : k7;
-            k0 = k0 < k2 ? k0 : k2;
-            k4 = k4 < k6 ? k4 : k6;
-            k0 = k0 < k4 ? k0 : k4;
-            best = k0 < best ? k0 : best;
+        if (nB >= 4) {
+            u32x8 g0[4], g1[4];
+            issue(g0, Bd);
+            wait(g0);
+            for (; j + 8 <= nB; j += 8) { // invariant: g0 = candidates j .. j+3, landed
+                issue(g1, Bd + j + 4);
+                group_min(g0, j);
+                wait(g1);
+                if (j + 12 <= nB) issue(g0, Bd + j + 8);
+                group_min(g1, j + 4);
+                wait(g0);
+            }
+            if (j + 4 <= nB) {
+                group_min(g0, j);
+                j += 4;
+            }
         }
         for (; j < nB; j++) {
-            const uint32_t k0 = candidate(j);
+            const Desc8 b = Bd[j];
+            u32x8 bv;
+#pragma unroll
+            for (int k = 0; k < 8; k++) bv[k] = b.w[k];
+            const uint32_t k0 = key_of(bv, j);
             best = k0 < best ? k0 : best;
         }
     }

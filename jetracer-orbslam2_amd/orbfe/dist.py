@@ -19,6 +19,37 @@ def shard_range(n_total, rank, world):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+class AsyncGather:
+    """Handle of an in-flight gather; wait() makes the current stream wait for it."""
+
+    def __init__(self, works, rec_all, cnt_all):
+        self.works, self.records, self.counts = works, rec_all, cnt_all
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        return self.records, self.counts
+
+
+def gather_keypoints_async(records, counts, out=None, dst=0, group=None):
+    """Like gather_keypoints but returns at once (async_op=True): the collective is ordered
+    after the work already queued on the current stream and overlaps what is queued next
+    (the following step's kernels).  `out` = (records_all, counts_all) buffers to reuse on dst."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return AsyncGather([], records.unsqueeze(0), counts.unsqueeze(0))
+    world = dist.get_world_size(group)
+    if dist.get_rank(group) == dst:
+        if out is None:
+            out = (torch.empty((world,) + tuple(records.shape), dtype=records.dtype, device=records.device),
+                   torch.empty((world,) + tuple(counts.shape), dtype=counts.dtype, device=counts.device))
+        w1 = dist.gather(counts, list(out[1].unbind(0)), dst=dst, group=group, async_op=True)
+        w2 = dist.gather(records, list(out[0].unbind(0)), dst=dst, group=group, async_op=True)
+        return AsyncGather([w1, w2], out[0], out[1])
+    w1 = dist.gather(counts, None, dst=dst, group=group, async_op=True)
+    w2 = dist.gather(records, None, dst=dst, group=group, async_op=True)
+    return AsyncGather([w1, w2], None, None)
+
+
 def gather_keypoints(records, counts, dst=0, group=None):
     """Gather fixed-stride record blocks and counts of every rank on `dst`.
 

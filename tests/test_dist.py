@@ -37,7 +37,7 @@ def _worker(rank, world, port, n_total, out_path):
         sys.path.insert(0, p)
     import oracle  # the CPU oracle stands in for the HIP extractor in this CPU-only test
     from orbfe import synth
-    from orbfe.dist import gather_keypoints, shard_range
+    from orbfe.dist import gather_keypoints, gather_keypoints_async, shard_range
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -53,6 +53,12 @@ def _worker(rank, world, port, n_total, out_path):
     rec_t = torch.from_numpy(rec.view(np.uint8).reshape(-1))
     cnt_t = torch.from_numpy(cnt)
     all_rec, all_cnt = gather_keypoints(rec_t, cnt_t, dst=0)
+    # the asynchronous form bench.py overlaps with the next step must deliver the same bytes
+    a_rec, a_cnt = gather_keypoints_async(rec_t, cnt_t, dst=0).wait()
+    if rank == 0:
+        assert torch.equal(a_rec, all_rec) and torch.equal(a_cnt, all_cnt)
+    else:
+        assert a_rec is None and a_cnt is None
     if rank == 0:
         np.savez(out_path, rec=all_rec.numpy(), cnt=all_cnt.numpy())
     else:
