@@ -270,8 +270,15 @@ __device__ inline int fast_score_packed(const uint8_t *p, uint32_t t2, int arc)
         const us2 ab = ssub(v, hi), ad = ssub(lo, v); // score terms v - (c+t), (c-t) - v, or 0
         sb += ab;
         sd += ad;
-        mb = mb * two + pmin(ab, one);
-        md = md * two + pmin(ad, one);
+        // mask = mask * 2 + (term != 0), as v_pk_min_u16 + v_pk_mad_u16.  Inline asm because hipcc
+        // rewrites min(x, 1) into per-half compare + select chains (3x the instructions).
+        uint32_t fb, fd, nb, nd;
+        asm("v_pk_min_u16 %0, %1, %2" : "=v"(fb) : "v"(U1(ab)), "v"(U1(one)));
+        asm("v_pk_min_u16 %0, %1, %2" : "=v"(fd) : "v"(U1(ad)), "v"(U1(one)));
+        asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(nb) : "v"(U1(mb)), "v"(U1(two)), "v"(fb));
+        asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(nd) : "v"(U1(md)), "v"(U1(two)), "v"(fd));
+        mb = U2(nb);
+        md = U2(nd);
     }
     const uint32_t ub = U1(mb), ud = U1(md);
     const uint32_t bright = (ub & 0xFFu) | ((ub >> 16) << 8), dark = (ud & 0xFFu) | ((ud >> 16) << 8);
@@ -287,10 +294,13 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr,
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_px32[kPxH * kPxDw];
     __shared__ __attribute__((aligned(16))) uint16_t s_sc[kScH * kScPitch];
-    __shared__ uint16_t s_q1[kScH * kPxW]; // candidates: r * kPxW + px
-    __shared__ uint16_t s_q2[kTileW * kTileH];
+    // per-wave queues (wave w owns the tasks tid = 64 w + lane of every trip): the fill level
+    // is a wave-uniform register, so compaction needs no atomics and no block barrier
+    constexpr int kTrips = (kScH * kPxDw + 255) / 256;  // task trips per wave
+    constexpr int kQ1 = kTrips * 64 * 4;                // candidates a wave can produce
+    __shared__ uint16_t s_q1[4][kQ1];                   // (r << 7) | px
+    __shared__ uint16_t s_q2[4][kQ1];                   // positives among them
     __shared__ uint32_t s_key[kMaxLdsCells];
-    __shared__ int s_n1, s_n2;
 
     int f, tile_id;
     xcd_remap(gridDim.x, gridDim.y, &f, &tile_id);
@@ -317,16 +327,15 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr,
     const int ncx = kTileW / c > 0 ? kTileW / c : 1, ncy = kTileH / c > 0 ? kTileH / c : 1;
     if (lds_cells)
         for (int i = tid; i < ncx * ncy; i += 256) s_key[i] = 0u;
-    if (tid == 0) {
-        s_n1 = 0;
-        s_n2 = 0;
-    }
     __syncthreads();
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint16_t *q1 = s_q1[wv], *q2 = s_q2[wv];
 
     // ---- B: compass pre-test, 4 pixels per lane; score-tile row r <-> image y0 - 1 + r,
     //         pixel-tile column px <-> image x0 - 4 + px
     const uint32_t t2 = (uint32_t)g.threshold * 0x00010001u;
     const bool need3 = g.arc >= 12;
+    int n1 = 0; // wave-uniform fill level of q1
     for (int task0 = 0; task0 < kScH * kPxDw; task0 += 256) {
         const int task = task0 + tid;
         uint32_t flags = 0;
@@ -358,26 +367,26 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr,
         const int incl = wave_incl_scan_i32(cnt);
         const int total = __builtin_amdgcn_readlane(incl, 63);
         if (total) {
-            int base = 0;
-            if (lane == 63) base = atomicAdd(&s_n1, total);
-            base = __builtin_amdgcn_readlane(base, 63);
-            int slot = base + incl - cnt;
+            int slot = n1 + incl - cnt;
 #pragma unroll
             for (int i = 0; i < 4; i++)
-                if (flags >> i & 1u) s_q1[slot++] = (uint16_t)(r * kPxW + 4 * q + i);
+                if (flags >> i & 1u) q1[slot++] = (uint16_t)((r << 7) | (4 * q + i));
+            n1 += total;
         }
     }
-    __syncthreads();
+    // (no block barrier: each wave consumes only its own queue; LDS ops of a wave are in order)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 
-    // ---- C: full ring test on the candidates
-    const int n1 = s_n1;
-    for (int i0 = 0; i0 < n1; i0 += 256) {
-        const int i = i0 + tid;
+    // ---- C: full ring test on the wave's candidates
+    int n2 = 0;
+    for (int i0 = 0; i0 < n1; i0 += 64) {
+        const int i = i0 + lane;
         bool pos = false;
         int e = 0;
         if (i < n1) {
-            e = s_q1[i];
-            const int r = e / kPxW, px = e - r * kPxW;
+            e = q1[i];
+            const int r = e >> 7, px = e & 127;
             const int sc = fast_score_packed(s_px + (r + 3) * kPxW + px, t2, g.arc);
             if (sc) {
                 s_sc[r * kScPitch + px - 3] = (uint16_t)sc;
@@ -385,20 +394,15 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr,
             }
         }
         const uint64_t m = __ballot(pos);
-        if (m) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&s_n2, (int)__popcll(m));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (pos) s_q2[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)e;
-        }
+        if (pos) q2[n2 + (int)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)e;
+        n2 += (int)__popcll(m);
     }
-    __syncthreads();
+    __syncthreads(); // every wave's scores are in s_sc
 
     // ---- D: strict 3x3 maximum on the positives, then the cell's maximum key
-    const int n2 = s_n2;
-    for (int i = tid; i < n2; i += 256) {
-        const int e = s_q2[i];
-        const int r = e / kPxW, px = e - r * kPxW;
+    for (int i = lane; i < n2; i += 64) {
+        const int e = q2[i];
+        const int r = e >> 7, px = e & 127;
         const uint16_t *q = &s_sc[r * kScPitch + px - 3];
         const int v = q[0];
         const bool is_max = v > q[-kScPitch] && v > q[-kScPitch + 1] && v > q[1] &&
