@@ -247,10 +247,11 @@ __device__ inline uint32_t compass4(uint32_t C, uint32_t Wd, uint32_t Ed, uint32
         const us2 m1 = pmin(a, cc), m2 = pmax(b, d);
         const us2 s2 = pmax(m1, m2), s3 = pmin(m1, m2); // 2nd and 3rd largest of the four
         const us2 bv = need3 ? s3 : s2, dv = need3 ? s2 : s3;
-        const uint32_t f = U1(ssub(bv, hi)) | U1(ssub(lo, dv)); // 16-bit lane != 0 <=> candidate
-        out |= ((f & 0xFFFFu) ? 1u : 0u) << h;
-        out |= ((f >> 16) ? 1u : 0u) << (2 + h);
+        uint32_t f = U1(ssub(bv, hi)) | U1(ssub(lo, dv)); // 16-bit lane != 0 <=> candidate
+        asm("v_pk_min_u16 %0, %1, %2" : "=v"(f) : "v"(f), "v"(0x00010001u)); // lanes -> 0 / 1
+        out |= f << h; // h = 0: bits 0 and 16 (pixels 0, 2); h = 1: bits 1 and 17 (pixels 1, 3)
     }
+    out = (out | (out >> 14)) & 0xFu; // bit i = pixel i
     return out;
 }
 
@@ -336,31 +337,50 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr,
     const uint32_t t2 = (uint32_t)g.threshold * 0x00010001u;
     const bool need3 = g.arc >= 12;
     int n1 = 0; // wave-uniform fill level of q1
-    for (int task0 = 0; task0 < kScH * kPxDw; task0 += 256) {
-        const int task = task0 + tid;
+    // Task = one dword group q (pixels px = 4q .. 4q+3) of score row r.  Trips 0 and 1 cover the
+    // tile proper (rows 1..32, groups 1..16: 512 tasks, no division in the mapping); trip 2 the
+    // 1-pixel halo ring (rows 0 and 33, and the single pixels px = 3 / px = 68 of every row).
+    // `inner` tiles (no image border inside the score tile) skip the per-pixel range tests.
+    const bool inner = x0 >= 4 && x0 + 64 < W - 3 && y0 >= 4 && y0 + 32 < H - 3;
+    for (int trip = 0; trip < kTrips; trip++) {
         uint32_t flags = 0;
-        int r = 0, q = 0;
-        if (task < kScH * kPxDw) {
-            r = task / kPxDw;
-            q = task - r * kPxDw;
+        int r, q;
+        uint32_t mask = 0xFu; // pixels of the group that belong to the score tile
+        if (trip < 2) {
+            q = (tid & 15) + 1;
+            r = (tid >> 4) + 1 + 16 * trip;
+        } else if (tid < 32) {
+            q = (tid & 15) + 1;
+            r = tid < 16 ? 0 : kScH - 1;
+        } else if (tid < 32 + kScH) {
+            q = 0;
+            r = tid - 32;
+            mask = 0x8u; // px = 3
+        } else if (tid < 32 + 2 * kScH) {
+            q = kPxDw - 1;
+            r = tid - 32 - kScH;
+            mask = 0x1u; // px = 68
+        } else {
+            q = 0;
+            r = 0;
+            mask = 0u;
+        }
+        if (!inner && mask) {
             const int y = y0 - 1 + r;
-            // valid pixels: 3 <= x < W - 3 and inside the score tile (px 3 .. 68)
             const int xb = x0 - 4 + 4 * q;
             int lo_i = 3 - xb, hi_i = W - 3 - xb; // pixel i valid iff lo_i <= i < hi_i
-            if (q == 0) lo_i = lo_i > 3 ? lo_i : 3;
-            if (q == kPxDw - 1) hi_i = hi_i < 1 ? hi_i : 1;
             lo_i = lo_i < 0 ? 0 : (lo_i > 4 ? 4 : lo_i);
             hi_i = hi_i < 0 ? 0 : (hi_i > 4 ? 4 : hi_i);
-            uint32_t valid = (y >= 3 && y < H - 3 && hi_i > lo_i) ? (((1u << hi_i) - 1u) & ~((1u << lo_i) - 1u)) : 0u;
-            if (valid) {
-                const uint32_t *row = s_px32 + (r + 3) * kPxDw;
-                const uint32_t C = row[q];
-                const uint32_t L = q > 0 ? row[q - 1] : 0u, Rr = q < kPxDw - 1 ? row[q + 1] : 0u;
-                const uint32_t Nd = row[q - 3 * kPxDw], Sd = row[q + 3 * kPxDw];
-                const uint32_t Wd = __builtin_amdgcn_alignbyte(C, L, 1);  // bytes x-3 of the 4 pixels
-                const uint32_t Ed = __builtin_amdgcn_alignbyte(Rr, C, 3); // bytes x+3
-                flags = compass4(C, Wd, Ed, Nd, Sd, t2, need3) & valid;
-            }
+            mask &= (y >= 3 && y < H - 3 && hi_i > lo_i) ? (((1u << hi_i) - 1u) & ~((1u << lo_i) - 1u)) : 0u;
+        }
+        if (mask) {
+            const uint32_t *row = s_px32 + (r + 3) * kPxDw;
+            const uint32_t C = row[q];
+            const uint32_t L = q > 0 ? row[q - 1] : 0u, Rr = q < kPxDw - 1 ? row[q + 1] : 0u;
+            const uint32_t Nd = row[q - 3 * kPxDw], Sd = row[q + 3 * kPxDw];
+            const uint32_t Wd = __builtin_amdgcn_alignbyte(C, L, 1);  // bytes x-3 of the 4 pixels
+            const uint32_t Ed = __builtin_amdgcn_alignbyte(Rr, C, 3); // bytes x+3
+            flags = compass4(C, Wd, Ed, Nd, Sd, t2, need3) & mask;
         }
         // wave-level compaction: inclusive scan of the per-lane candidate counts
         const int cnt = __popc(flags);
