@@ -569,6 +569,11 @@ select_kernel(DeviceGeom g, const uint32_t *__restrict__ cellkey, uint4 *__restr
 // gathers); moments and the 512 descriptor samples then read LDS bytes.
 constexpr int kKpw = 4; // keypoints per wave (consecutive slots = neighbouring cells)
 
+// One wave = kKpw keypoints, in three passes so that the transcendental math is not repeated
+// by all 64 lanes for every keypoint:
+//   1  stage the kKpw patches in LDS and reduce their moments (wave-uniform integers)
+//   2  lanes 0..kKpw-1 each take one keypoint: atan2f, steering cos/sin -- ONCE per wave
+//   3  per keypoint: 256 rotated tests from its LDS patch, 4 ballots = the descriptor
 template <int R>
 __global__ void __launch_bounds__(256)
 describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__restrict__ sel,
@@ -576,71 +581,98 @@ describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__re
 {
     constexpr int kRows = 2 * R + 1;
     constexpr int kDw = (2 * R + 3) / 4 + 1; // dwords per patch row incl. alignment slack
-    __shared__ uint32_t s_patch[4][kRows * kDw];
+    constexpr int kPatch = kRows * kDw;
+    __shared__ uint32_t s_patch[4][kKpw][kPatch];
 
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // scalar: wave-uniform
     int f, blk;
     xcd_remap(gridDim.x, gridDim.y, &f, &blk);
     const int n = selcount[f];
+    const int slot0 = (blk * 4 + wv) * kKpw; // wave-uniform
+    if (slot0 >= n) return;
+    const int nk = n - slot0 < kKpw ? n - slot0 : kKpw;
     const uint8_t *img = pyr + (size_t)f * g.frame_stride + g.lv[0].offset;
     const int P = g.lv[0].pitch;
-    const uint4 *fsel = sel + (size_t)f * g.cap;
-    uint32_t *sp = s_patch[wv];
-    const uint8_t *spb = reinterpret_cast<const uint8_t *>(sp);
+    const uint4 *fsel = sel + (size_t)f * g.cap + slot0;
 
+    int kx[kKpw], ky[kKpw], kax[kKpw], m10[kKpw], m01[kKpw];
+    uint32_t kcell[kKpw], kkey[kKpw];
+    // ---- pass 1: stage + moments
+#pragma unroll
     for (int it = 0; it < kKpw; it++) {
-        const int slot = (blk * 4 + wv) * kKpw + it; // wave-uniform
-        if (slot >= n) break;
-        const uint4 sr = fsel[slot]; // uniform address: scalar load
-        const int cell = (int)sr.x, x = (int)(sr.y & 0xFFFFu), y = (int)(sr.y >> 16);
-        const int score = (int)(sr.z >> 15), level = 7 - (int)((sr.z >> 12) & 7u);
-
+        kx[it] = ky[it] = kax[it] = m10[it] = m01[it] = 0;
+        kcell[it] = kkey[it] = 0;
+        if (it >= nk) continue; // uniform
+        const uint4 sr = fsel[it]; // uniform address: scalar load
+        kcell[it] = sr.x;
+        kkey[it] = sr.z;
+        const int x = (int)(sr.y & 0xFFFFu), y = (int)(sr.y >> 16);
+        kx[it] = x;
+        ky[it] = y;
         const int oy = y - R;
         const int ax = (x - R) & ~3; // x >= 3, R <= 19: may be negative, still a multiple of 4
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // previous keypoint's reads are done
-        __builtin_amdgcn_wave_barrier();
-        {
-            // dword i of the patch = (row i / kDw, column dword i % kDw); i advances by 64 per
-            // trip, so (row, dword) advance by (64 / kDw, 64 % kDw) with one carry: no divisions
-            int r = lane / kDw, q = lane - r * kDw;
+        kax[it] = ax;
+        uint32_t *sp = s_patch[wv][it];
+        // dword i of the patch = (row i / kDw, column dword i % kDw); i advances by 64 per trip,
+        // so (row, dword) advance by (64 / kDw, 64 % kDw) with one carry: no divisions
+        int r = lane / kDw, q = lane - r * kDw;
 #pragma unroll
-            for (int i0 = 0; i0 < kRows * kDw; i0 += 64) {
-                const int i = i0 + lane;
-                const int gy = oy + r, gx = ax + 4 * q;
-                uint32_t v = 0;
-                // pixels the moments exclude (row <= 0, row >= H, column <= 0, column >= W) are
-                // staged as 0; the descriptor never samples them (17-px guard band)
-                if (i < kRows * kDw && gy > 0 && gy < g.H && gx >= 0 && gx < g.W) {
-                    v = *reinterpret_cast<const uint32_t *>(img + (uint32_t)(__mul24(gy, P) + gx));
-                    if (gx == 0) v &= 0xFFFFFF00u;
-                    const int nv = g.W - gx; // valid bytes in this dword
-                    if (nv < 4) v &= (1u << (8 * nv)) - 1u;
-                }
-                if (i < kRows * kDw) sp[i] = v;
-                r += 64 / kDw;
-                q += 64 % kDw;
-                if (q >= kDw) {
-                    q -= kDw;
-                    r += 1;
-                }
+        for (int i0 = 0; i0 < kPatch; i0 += 64) {
+            const int i = i0 + lane;
+            const int gy = oy + r, gx = ax + 4 * q;
+            uint32_t v = 0;
+            // pixels the moments exclude (row <= 0, row >= H, column <= 0, column >= W) are
+            // staged as 0; the descriptor never samples them (17-px guard band)
+            if (i < kPatch && gy > 0 && gy < g.H && gx >= 0 && gx < g.W) {
+                v = *reinterpret_cast<const uint32_t *>(img + (uint32_t)(__mul24(gy, P) + gx));
+                if (gx == 0) v &= 0xFFFFFF00u;
+                const int nv = g.W - gx; // valid bytes in this dword
+                if (nv < 4) v &= (1u << (8 * nv)) - 1u;
+            }
+            if (i < kPatch) sp[i] = v;
+            r += 64 / kDw;
+            q += 64 % kDw;
+            if (q >= kDw) {
+                q -= kDw;
+                r += 1;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const LdsPatch px{spb, kDw * 4, oy, ax};
-
-        int m10, m01;
-        patch_moments_staged(spb + R * (kDw * 4) + (x - ax), kDw * 4, lane, &m10, &m01);
-        const float angle = orbfe_atan2f((float)m01, (float)m10);
-
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // LDS ops of one wave are in order
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < kKpw; it++) {
+        if (it >= nk) continue;
+        const uint8_t *spb = reinterpret_cast<const uint8_t *>(s_patch[wv][it]);
+        patch_moments_staged(spb + R * (kDw * 4) + (kx[it] - kax[it]), kDw * 4, lane, &m10[it], &m01[it]);
+    }
+    // ---- pass 2: lane `it` owns keypoint `it`
+    int lm10 = m10[0], lm01 = m01[0];
+#pragma unroll
+    for (int it = 1; it < kKpw; it++) {
+        lm10 = lane == it ? m10[it] : lm10;
+        lm01 = lane == it ? m01[it] : lm01;
+    }
+    const float langle = orbfe_atan2f((float)lm01, (float)lm10);
+    float la, lb;
+    orb_steer(langle, g.angle_in_radians, &la, &lb);
+    // ---- pass 3: descriptors + records
+#pragma unroll
+    for (int it = 0; it < kKpw; it++) {
+        if (it >= nk) continue;
+        const float angle = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(langle), it));
+        const float a = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(la), it));
+        const float b = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(lb), it));
+        const int x = kx[it], y = ky[it];
+        const LdsPatch px{reinterpret_cast<const uint8_t *>(s_patch[wv][it]), kDw * 4, y - R, kax[it]};
         uint64_t d[4] = {0, 0, 0, 0};
-        if (!orb_border_zero(x, y, g.W, g.H, g.angle_in_radians))
-            orb_describe(px, x, y, angle, g.angle_in_radians, lane, d);
+        if (!orb_border_zero(x, y, g.W, g.H, g.angle_in_radians)) orb_describe(px, x, y, a, b, lane, d);
 
         // every value is wave-uniform: lane 0 stores the 13 dwords of the record
         if (lane == 0) {
-            uint32_t *rec = reinterpret_cast<uint32_t *>(records + (size_t)f * g.cap + slot);
+            const int score = (int)(kkey[it] >> 15), level = 7 - (int)((kkey[it] >> 12) & 7u);
+            uint32_t *rec = reinterpret_cast<uint32_t *>(records + (size_t)f * g.cap + slot0 + it);
             rec[0] = __float_as_uint((float)x);
             rec[1] = __float_as_uint((float)y);
             rec[2] = __float_as_uint((float)score);
@@ -652,7 +684,7 @@ describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__re
                 rec[6 + 2 * k] = (uint32_t)(d[k] >> 32);
             }
             if (soa.d_angle || soa.d_desc32 || soa.d_desc) {
-                const size_t o = (size_t)f * g.K + cell;
+                const size_t o = (size_t)f * g.K + kcell[it];
                 if (soa.d_angle) soa.d_angle[o] = angle;
                 if (soa.d_desc32) soa.d_desc32[o] = orb_compress(d);
                 if (soa.d_desc) {

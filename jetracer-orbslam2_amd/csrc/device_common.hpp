@@ -164,14 +164,11 @@ __device__ inline bool orb_border_zero(int lx, int ly, int w, int h, int radians
                    : (lx < 17 || lx > w - 17 || ly < 17 || ly > h - 17);
 }
 
+// (a, b) = (cos, sin) of the steering angle (orb_steer below)
 template <typename Px>
-__device__ inline void orb_describe(const Px &px, int lx, int ly, float angle, int radians, int lane,
-                                    uint64_t d[4])
+__device__ inline void orb_describe(const Px &px, int lx, int ly, float a, float b, int lane, uint64_t d[4])
 {
     ORBFE_NO_CONTRACT
-    const float ang = radians ? angle : angle * ORBFE_DEG2RAD_F;
-    float a, b;
-    orbfe_sincosf(ang, &b, &a); // a = cos, b = sin
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const float4 pt = reinterpret_cast<const float4 *>(c_pattern_f)[64 * r + lane];
@@ -184,6 +181,15 @@ __device__ inline void orb_describe(const Px &px, int lx, int ly, float angle, i
         const int t1 = px(qrow, qcol);
         d[r] = __ballot(t0 < t1);
     }
+}
+
+// cos / sin of the descriptor steering angle: the stored angle (radians) times pi/180 in the
+// reference (Q7), or the angle itself with angle_in_radians.
+__device__ inline void orb_steer(float angle, int radians, float *a, float *b)
+{
+    ORBFE_NO_CONTRACT
+    const float ang = radians ? angle : angle * ORBFE_DEG2RAD_F;
+    orbfe_sincosf(ang, b, a);
 }
 
 __device__ inline uint32_t orb_compress(const uint64_t d[4])

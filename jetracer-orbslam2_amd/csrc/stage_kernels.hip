@@ -210,8 +210,11 @@ __global__ void calc_orb_kernel(const float *__restrict__ d_angle, const float *
     if (idx >= n) return;
     const int lx = (int)(short)d_pos[2 * idx], ly = (int)(short)d_pos[2 * idx + 1];
     uint64_t d[4] = {0, 0, 0, 0};
-    if (!orb_border_zero(lx, ly, w, h, radians))
-        orb_describe(GlobalPx{img, pitch}, lx, ly, d_angle[idx], radians, lane, d);
+    if (!orb_border_zero(lx, ly, w, h, radians)) {
+        float a, b;
+        orb_steer(d_angle[idx], radians, &a, &b);
+        orb_describe(GlobalPx{img, pitch}, lx, ly, a, b, lane, d);
+    }
     if (lane < 4) reinterpret_cast<uint64_t *>(d_desc + (size_t)idx * 32)[lane] = d[lane];
     if (lane == 0 && d_desc32) d_desc32[idx] = orb_compress(d);
 }
