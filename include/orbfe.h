@@ -198,6 +198,20 @@ int orbfe_build_pyramid(orbfe_ctx *ctx, const uint8_t *d_gray, size_t pitch,
  * detection levels (levels with cell >> level >= 1) of n_frames frames. */
 int orbfe_detect_batch(orbfe_ctx *ctx, int n_frames, orbfe_stream_t stream);
 
+/* Sharded detection (one large frame over several GPUs, SURVEY.md 8e "per-level shard"):
+ * run only the detection tiles shard_index, shard_index + shard_count, ... (tiles of all
+ * levels, interleaved).  Each shard yields a partial per-cell key array; because the key
+ * encodes score, level and the reference's tie order, the exact result is the element-wise
+ * unsigned MAXIMUM of the shards' arrays, in any order: export, all-reduce(MAX) over RCCL,
+ * import, then orbfe_describe_batch.  Keys are < 2^27, so a signed-int32 MAX is equivalent. */
+int orbfe_detect_batch_shard(orbfe_ctx *ctx, int n_frames, int shard_index, int shard_count,
+                             orbfe_stream_t stream);
+/* Copy the n_frames * K cell keys of the last detection out of / into the context (device to
+ * device, on `stream`). */
+int orbfe_export_cell_keys(orbfe_ctx *ctx, int n_frames, uint32_t *d_keys, orbfe_stream_t stream);
+int orbfe_import_cell_keys(orbfe_ctx *ctx, int n_frames, const uint32_t *d_keys,
+                           orbfe_stream_t stream);
+
 /* selection (all non-empty cells or top-N) + a8 orientation + a9/a10 descriptors for the
  * frames last detected; outputs as orbfe_extract. */
 int orbfe_describe_batch(orbfe_ctx *ctx, int n_frames, orbfe_keypoint *d_records,

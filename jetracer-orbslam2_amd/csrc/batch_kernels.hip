@@ -290,8 +290,8 @@ __device__ inline int fast_score_packed(const uint8_t *p, uint32_t t2, int arc)
 }
 
 __global__ void __launch_bounds__(256)
-detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr,
-                   const TileDesc *__restrict__ tiles, uint32_t *__restrict__ cellkey)
+detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc *__restrict__ tiles,
+                   uint32_t *__restrict__ cellkey, int tile_first, int tile_step)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_px32[kPxH * kPxDw];
     __shared__ __attribute__((aligned(16))) uint16_t s_sc[kScH * kScPitch];
@@ -305,7 +305,7 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr,
 
     int f, tile_id;
     xcd_remap(gridDim.x, gridDim.y, &f, &tile_id);
-    const TileDesc td = tiles[tile_id];
+    const TileDesc td = tiles[tile_first + tile_id * tile_step]; // shard: every tile_step-th tile
     const int l = td.level;
     const int W = g.lv[l].w, H = g.lv[l].h, P = g.lv[l].pitch;
     const uint8_t *img = pyr + (size_t)f * g.frame_stride + g.lv[l].offset;
@@ -1093,19 +1093,50 @@ int orbfe_build_pyramid(orbfe_ctx *ctx, const uint8_t *d_gray, size_t pitch, siz
     return ORBFE_OK;
 }
 
-int orbfe_detect_batch(orbfe_ctx *ctx, int n_frames, orbfe_stream_t stream)
+int orbfe_detect_batch_shard(orbfe_ctx *ctx, int n_frames, int shard_index, int shard_count,
+                             orbfe_stream_t stream)
 {
     if (!ctx) return ORBFE_ERR_INVALID_ARG;
     if (n_frames < 1) CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "detect_batch: n_frames %d", n_frames);
+    if (shard_count < 1 || shard_index < 0 || shard_index >= shard_count)
+        CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "detect_batch: shard %d of %d", shard_index, shard_count);
     if (n_frames > ctx->cfg.max_batch)
         CTX_FAIL(ctx, ORBFE_ERR_CAPACITY, "detect_batch: n_frames %d > max_batch %d", n_frames, ctx->cfg.max_batch);
     const DeviceGeom &g = ctx->g;
     ORBFE_HIP_TRY(ctx->err, hipSetDevice(ctx->cfg.device));
     ORBFE_HIP_TRY(ctx->err, hipMemsetAsync(ctx->d_cellkey, 0, (size_t)n_frames * g.K * sizeof(uint32_t), S(stream)));
-    if (ctx->n_tiles > 0)
-        hipLaunchKernelGGL(detect_tile_kernel, dim3(ctx->n_tiles, n_frames), dim3(256), 0, S(stream), g,
-                           ctx->d_pyr, ctx->d_tiles, ctx->d_cellkey);
+    // tiles shard_index, shard_index + shard_count, ... (interleaved: every shard gets a mix of
+    // levels and of busy / empty image regions)
+    const int n_mine = ctx->n_tiles > shard_index ? (ctx->n_tiles - shard_index + shard_count - 1) / shard_count : 0;
+    if (n_mine > 0)
+        hipLaunchKernelGGL(detect_tile_kernel, dim3(n_mine, n_frames), dim3(256), 0, S(stream), g, ctx->d_pyr,
+                           ctx->d_tiles, ctx->d_cellkey, shard_index, shard_count);
     CTX_LAUNCH_CHECK(ctx, "detect_batch");
+    return ORBFE_OK;
+}
+
+int orbfe_detect_batch(orbfe_ctx *ctx, int n_frames, orbfe_stream_t stream)
+{
+    return orbfe_detect_batch_shard(ctx, n_frames, 0, 1, stream);
+}
+
+int orbfe_export_cell_keys(orbfe_ctx *ctx, int n_frames, uint32_t *d_keys, orbfe_stream_t stream)
+{
+    if (!ctx) return ORBFE_ERR_INVALID_ARG;
+    if (!d_keys || n_frames < 1 || n_frames > ctx->cfg.max_batch)
+        CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "export_cell_keys: bad argument");
+    ORBFE_HIP_TRY(ctx->err, hipMemcpyAsync(d_keys, ctx->d_cellkey, (size_t)n_frames * ctx->g.K * sizeof(uint32_t),
+                                           hipMemcpyDeviceToDevice, S(stream)));
+    return ORBFE_OK;
+}
+
+int orbfe_import_cell_keys(orbfe_ctx *ctx, int n_frames, const uint32_t *d_keys, orbfe_stream_t stream)
+{
+    if (!ctx) return ORBFE_ERR_INVALID_ARG;
+    if (!d_keys || n_frames < 1 || n_frames > ctx->cfg.max_batch)
+        CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "import_cell_keys: bad argument");
+    ORBFE_HIP_TRY(ctx->err, hipMemcpyAsync(ctx->d_cellkey, d_keys, (size_t)n_frames * ctx->g.K * sizeof(uint32_t),
+                                           hipMemcpyDeviceToDevice, S(stream)));
     return ORBFE_OK;
 }
 

@@ -85,6 +85,9 @@ _SIGS = {
     "orbfe_build_pyramid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int,
                                       C.c_void_p]),
     "orbfe_detect_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "orbfe_detect_batch_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "orbfe_export_cell_keys": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "orbfe_import_cell_keys": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "orbfe_describe_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                        C.POINTER(Soa), C.c_void_p]),
     "orbfe_extract": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int,
@@ -176,6 +179,16 @@ class Context:
 
     def detect_batch(self, n_frames, stream=0):
         check(lib().orbfe_detect_batch(self.handle, n_frames, stream), self.handle)
+
+    def detect_batch_shard(self, n_frames, shard_index, shard_count, stream=0):
+        check(lib().orbfe_detect_batch_shard(self.handle, n_frames, shard_index, shard_count, stream),
+              self.handle)
+
+    def export_cell_keys(self, n_frames, d_keys, stream=0):
+        check(lib().orbfe_export_cell_keys(self.handle, n_frames, d_keys, stream), self.handle)
+
+    def import_cell_keys(self, n_frames, d_keys, stream=0):
+        check(lib().orbfe_import_cell_keys(self.handle, n_frames, d_keys, stream), self.handle)
 
     def describe_batch(self, n_frames, d_records, d_counts, soa=None, stream=0):
         check(lib().orbfe_describe_batch(self.handle, n_frames, d_records, d_counts,

@@ -71,3 +71,12 @@ def gather_keypoints(records, counts, dst=0, group=None):
     dist.gather(counts, None, dst=dst, group=group)
     dist.gather(records, None, dst=dst, group=group)
     return None, None
+
+
+def merge_cell_keys(keys, group=None):
+    """All-reduce(MAX) of per-cell detection keys across ranks (tile-sharded detection of one
+    large frame, orbfe_detect_batch_shard).  keys: int32 tensor viewing the uint32 keys (all
+    < 2**27, so signed MAX == unsigned MAX).  In place; identity without a process group."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(keys, op=dist.ReduceOp.MAX, group=group)
+    return keys

@@ -37,7 +37,7 @@ def _worker(rank, world, port, n_total, out_path):
         sys.path.insert(0, p)
     import oracle  # the CPU oracle stands in for the HIP extractor in this CPU-only test
     from orbfe import synth
-    from orbfe.dist import gather_keypoints, gather_keypoints_async, shard_range
+    from orbfe.dist import gather_keypoints, gather_keypoints_async, merge_cell_keys, shard_range
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -63,6 +63,16 @@ def _worker(rank, world, port, n_total, out_path):
         np.savez(out_path, rec=all_rec.numpy(), cnt=all_cnt.numpy())
     else:
         assert all_rec is None and all_cnt is None
+    # tile-sharded detection: partial per-cell keys merge by all-reduce(MAX)
+    g = torch.Generator().manual_seed(7)
+    full = torch.randint(0, 2 ** 27, (world, 500), generator=g, dtype=torch.int32)
+    mine = full[rank].clone()
+    mine[torch.arange(500) % world != rank] //= 3  # each rank holds the winner of "its" cells
+    want = torch.stack([full[r].clone() for r in range(world)])
+    for r in range(world):
+        want[r][torch.arange(500) % world != r] //= 3
+    merged = merge_cell_keys(mine)
+    assert torch.equal(merged, want.max(0).values)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -479,3 +479,36 @@ def test_full_size_batch_properties(gpu, oracle_mod):
         ref = oracle_mod.extract_frame(frames[f], ocfg)
         assert cnt[f] == ref["count"]
         assert rec[f, :cnt[f]].tobytes() == ref["records"].tobytes()
+
+
+# ------------------------------------------------------------------ tile-sharded detection (C5)
+@pytest.mark.parametrize("w,h,levels,shards", [(3840, 2160, 12, 8), (640, 480, 6, 3)])
+def test_tile_sharded_detection_merges_exactly(gpu, oracle_mod, w, h, levels, shards):
+    """BASELINE configs[4]: one 4K frame, 12 levels built, K = 8160 cells, detection tiles
+    sharded 8 ways.  Each shard produces partial cell keys; their element-wise maximum (what an
+    all-reduce(MAX) over RCCL computes) followed by describe must equal the unsharded result and
+    the oracle, bit for bit.  Shards run one after another on the single test GPU."""
+    torch, orbfe = gpu
+    img = synth.frame(w, h, 12, "rects", n_rects=800 * (w * h) // (640 * 480), min_size=6, max_size=32)
+    ctx = orbfe.Context(w, h, levels=levels, max_batch=1)
+    d_in = dev(torch, img)
+    s = stream(torch)
+    ctx.build_pyramid(d_in.data_ptr(), w, w * h, 1, s)
+    merged = torch.zeros(ctx.K, dtype=torch.int32, device="cuda")
+    part = torch.zeros(ctx.K, dtype=torch.int32, device="cuda")
+    nonempty = []
+    for i in range(shards):
+        ctx.detect_batch_shard(1, i, shards, s)
+        ctx.export_cell_keys(1, part.data_ptr(), s)
+        nonempty.append(int((part > 0).sum()))
+        merged = torch.maximum(merged, part)          # == dist.all_reduce(op=MAX)
+    ctx.import_cell_keys(1, merged.data_ptr(), s)
+    rec = torch.zeros(ctx.cap * 52, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ctx.describe_batch(1, rec.data_ptr(), cnt.data_ptr(), None, s)
+    torch.cuda.synchronize()
+    ref = oracle_mod.extract_frame(img, oracle_mod.make_config(w, h, levels=levels))
+    n = int(cnt.cpu()[0])
+    assert n == ref["count"] and n > ctx.K // 2
+    assert rec.cpu().numpy().view(orbfe.KEYPOINT_DTYPE)[:n].tobytes() == ref["records"].tobytes()
+    assert min(nonempty) > 0 and max(nonempty) < n, "every shard contributes, none sees everything"
