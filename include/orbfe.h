@@ -65,6 +65,11 @@ enum {
 
 /* ================= stage API: one frame, caller-owned buffers, reference semantics ===== */
 
+/* rgb_to_grayscale, src/cuda/cuda_RGB_to_Grayscale.cuh:10-16 (the step right
+ * before the path): dst = floor((B*0.07 + G*0.72 + R*0.21) + 0.5) in double, interleaved RGB8. */
+int orbfe_rgb_to_grayscale(unsigned char *d_dst, const unsigned char *d_src, int cols, int rows,
+                           int dst_pitch, int src_pitch, orbfe_stream_t stream);
+
 /* gaussian_blur_3x3, src/cuda/orb.cuh:29-35.  Rows 0, h-2, h-1 are written as 0. */
 int orbfe_gaussian_blur_3x3(unsigned char *d_blurred, int blurred_pitch,
                             const unsigned char *d_image, int image_pitch, int image_width,
@@ -194,6 +199,12 @@ int orbfe_level_info(const orbfe_ctx *ctx, int level, int *width, int *height, s
 int orbfe_build_pyramid(orbfe_ctx *ctx, const uint8_t *d_gray, size_t pitch,
                         size_t frame_stride, int n_frames, orbfe_stream_t stream);
 
+/* The same from interleaved RGB8 frames (pitch >= 3 * width): the gray conversion is fused
+ * into the pyramid kernel's row loads, the gray frame is never written.  Needs width % 4 == 0
+ * and a 4-byte aligned source, else ORBFE_ERR_UNSUPPORTED. */
+int orbfe_build_pyramid_rgb(orbfe_ctx *ctx, const uint8_t *d_rgb, size_t pitch, size_t frame_stride,
+                            int n_frames, orbfe_stream_t stream);
+
 /* a4..a7 on the context's pyramid: fused FAST score + 3x3 NMS + per-cell maximum over all
  * detection levels (levels with cell >> level >= 1) of n_frames frames. */
 int orbfe_detect_batch(orbfe_ctx *ctx, int n_frames, orbfe_stream_t stream);
@@ -224,6 +235,11 @@ int orbfe_describe_batch(orbfe_ctx *ctx, int n_frames, orbfe_keypoint *d_records
 int orbfe_extract(orbfe_ctx *ctx, const uint8_t *d_gray, size_t pitch, size_t frame_stride,
                   int n_frames, orbfe_keypoint *d_records, int32_t *d_counts,
                   const orbfe_soa *soa, orbfe_stream_t stream);
+
+/* orbfe_extract with interleaved RGB8 input (orbfe_build_pyramid_rgb + detect + describe). */
+int orbfe_extract_rgb(orbfe_ctx *ctx, const uint8_t *d_rgb, size_t pitch, size_t frame_stride,
+                      int n_frames, orbfe_keypoint *d_records, int32_t *d_counts,
+                      const orbfe_soa *soa, orbfe_stream_t stream);
 
 /* a11 over a batch: for f = 1 .. n_frames-1 match the records of frame f-1 (prev) against
  * frame f (curr).  mode 0 = reference semantics (32-bit word, +-window px, distance <

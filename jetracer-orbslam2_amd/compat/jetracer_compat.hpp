@@ -36,6 +36,14 @@ inline void check(int rc, const char *what)
 inline orbfe_stream_t S(hipStream_t s) { return reinterpret_cast<orbfe_stream_t>(s); }
 } // namespace detail
 
+// src/cuda/cuda_RGB_to_Grayscale.cuh:10-16
+inline void rgb_to_grayscale(unsigned char *dst, unsigned char *src, int cols, int rows, int dst_pitch,
+                             int src_pitch, hipStream_t stream)
+{
+    detail::check(orbfe_rgb_to_grayscale(dst, src, cols, rows, dst_pitch, src_pitch, detail::S(stream)),
+                  "rgb_to_grayscale");
+}
+
 // src/cuda/orb.cuh:29-35
 inline void gaussian_blur_3x3(unsigned char *blurred_image, int blurred_image_pitch, unsigned char *image,
                               int image_pitch, int image_width, int image_height, hipStream_t stream)

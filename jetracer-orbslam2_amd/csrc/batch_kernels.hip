@@ -105,6 +105,9 @@ halfsample_batch_kernel(uint8_t *__restrict__ pyr, size_t fstride, size_t src_of
 // stream by; level 2 goes to LDS and levels 3..7 are a five-step LDS cascade.
 // Requires W % 4 == 0 and a dword-aligned source; otherwise the unfused kernels above run.
 // ------------------------------------------------------------------------------------
+// RGB = the source is interleaved RGB8 (f1): the gray conversion happens in the row load, so
+// the gray frame never exists in HBM.
+template <bool RGB>
 __global__ void __launch_bounds__(256)
 pyramid_fused_kernel(DeviceGeom g, uint8_t *__restrict__ pyr, const uint8_t *__restrict__ src, int src_pitch,
                      size_t src_fstride, int tiles_x)
@@ -126,7 +129,14 @@ pyramid_fused_kernel(DeviceGeom g, uint8_t *__restrict__ pyr, const uint8_t *__r
     // horizontal 1-2-1 sums of input row yy, as (even pixels, odd pixels) 16-bit lane pairs
     auto hrow = [&](int yy, uint32_t &hE, uint32_t &hO) {
         uint32_t v = 0;
-        if (col_ok && yy >= 0 && yy < H) v = *reinterpret_cast<const uint32_t *>(src + (size_t)yy * src_pitch + x0);
+        if (col_ok && yy >= 0 && yy < H) {
+            if (RGB) {
+                const uint32_t *p3 = reinterpret_cast<const uint32_t *>(src + (size_t)yy * src_pitch + 3 * x0);
+                v = rgb4_to_gray4(p3[0], p3[1], p3[2]);
+            } else {
+                v = *reinterpret_cast<const uint32_t *>(src + (size_t)yy * src_pitch + x0);
+            }
+        }
         const uint32_t Ld = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true); // lane - 1
         const uint32_t Rd = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xF, 0xF, true); // lane + 1
         const uint32_t Lb = seam_l ? (v & 0xFFu) : (Ld >> 24);
@@ -1056,31 +1066,39 @@ int orbfe_level_info(const orbfe_ctx *ctx, int level, int *width, int *height, s
     return ORBFE_OK;
 }
 
-int orbfe_build_pyramid(orbfe_ctx *ctx, const uint8_t *d_gray, size_t pitch, size_t frame_stride,
-                        int n_frames, orbfe_stream_t stream)
+static int build_pyramid_impl(orbfe_ctx *ctx, const uint8_t *d_src, size_t pitch, size_t frame_stride, int n_frames,
+                              bool rgb, orbfe_stream_t stream)
 {
     if (!ctx) return ORBFE_ERR_INVALID_ARG;
     const DeviceGeom &g = ctx->g;
-    if (!d_gray || n_frames < 1 || pitch < (size_t)g.W || (n_frames > 1 && frame_stride < pitch * (size_t)g.H))
+    const size_t row_bytes = rgb ? 3 * (size_t)g.W : (size_t)g.W;
+    if (!d_src || n_frames < 1 || pitch < row_bytes || (n_frames > 1 && frame_stride < pitch * (size_t)g.H))
         CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "build_pyramid: bad input geometry");
     if (n_frames > ctx->cfg.max_batch)
         CTX_FAIL(ctx, ORBFE_ERR_CAPACITY, "build_pyramid: n_frames %d > max_batch %d", n_frames, ctx->cfg.max_batch);
     ORBFE_HIP_TRY(ctx->err, hipSetDevice(ctx->cfg.device));
-    const bool vec = (pitch % 4 == 0) && (frame_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_gray) & 3u) == 0);
+    const bool vec = (pitch % 4 == 0) && (frame_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_src) & 3u) == 0);
+    if (rgb && !(vec && g.W % 4 == 0))
+        CTX_FAIL(ctx, ORBFE_ERR_UNSUPPORTED, "build_pyramid_rgb: needs width %% 4 == 0 and a 4-byte aligned source "
+                 "(use orbfe_rgb_to_grayscale + orbfe_build_pyramid otherwise)");
     int next_level = 1; // first level still to be produced by the unfused halving kernel
     if (vec && g.W % 4 == 0) {
         const int tiles_x = (g.W + 127) / 128, tiles_y = (g.H + 127) / 128;
-        hipLaunchKernelGGL(pyramid_fused_kernel, dim3(tiles_x * tiles_y, n_frames), dim3(256), 0, S(stream), g,
-                           ctx->d_pyr, d_gray, (int)pitch, frame_stride, tiles_x);
+        if (rgb)
+            hipLaunchKernelGGL(pyramid_fused_kernel<true>, dim3(tiles_x * tiles_y, n_frames), dim3(256), 0, S(stream),
+                               g, ctx->d_pyr, d_src, (int)pitch, frame_stride, tiles_x);
+        else
+            hipLaunchKernelGGL(pyramid_fused_kernel<false>, dim3(tiles_x * tiles_y, n_frames), dim3(256), 0, S(stream),
+                               g, ctx->d_pyr, d_src, (int)pitch, frame_stride, tiles_x);
         next_level = 8;
     } else {
         dim3 grid(((g.W + 255) / 256) * ((g.H + 3) / 4), n_frames), block(256);
         if (vec)
             hipLaunchKernelGGL(blur_batch_kernel<true>, grid, block, 0, S(stream), ctx->d_pyr + g.lv[0].offset,
-                               g.lv[0].pitch, g.frame_stride, d_gray, (int)pitch, frame_stride, g.W, g.H);
+                               g.lv[0].pitch, g.frame_stride, d_src, (int)pitch, frame_stride, g.W, g.H);
         else
             hipLaunchKernelGGL(blur_batch_kernel<false>, grid, block, 0, S(stream), ctx->d_pyr + g.lv[0].offset,
-                               g.lv[0].pitch, g.frame_stride, d_gray, (int)pitch, frame_stride, g.W, g.H);
+                               g.lv[0].pitch, g.frame_stride, d_src, (int)pitch, frame_stride, g.W, g.H);
     }
     for (int l = next_level; l < g.L; l++) {
         const int dw = g.lv[l].w, dh = g.lv[l].h;
@@ -1091,6 +1109,18 @@ int orbfe_build_pyramid(orbfe_ctx *ctx, const uint8_t *d_gray, size_t pitch, siz
     }
     CTX_LAUNCH_CHECK(ctx, "build_pyramid");
     return ORBFE_OK;
+}
+
+int orbfe_build_pyramid(orbfe_ctx *ctx, const uint8_t *d_gray, size_t pitch, size_t frame_stride, int n_frames,
+                        orbfe_stream_t stream)
+{
+    return build_pyramid_impl(ctx, d_gray, pitch, frame_stride, n_frames, false, stream);
+}
+
+int orbfe_build_pyramid_rgb(orbfe_ctx *ctx, const uint8_t *d_rgb, size_t pitch, size_t frame_stride, int n_frames,
+                            orbfe_stream_t stream)
+{
+    return build_pyramid_impl(ctx, d_rgb, pitch, frame_stride, n_frames, true, stream);
 }
 
 int orbfe_detect_batch_shard(orbfe_ctx *ctx, int n_frames, int shard_index, int shard_count,
@@ -1173,6 +1203,17 @@ int orbfe_extract(orbfe_ctx *ctx, const uint8_t *d_gray, size_t pitch, size_t fr
     if (!ctx) return ORBFE_ERR_INVALID_ARG;
     if (!d_records || !d_counts) CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "extract: null output");
     int rc = orbfe_build_pyramid(ctx, d_gray, pitch, frame_stride, n_frames, stream);
+    if (rc == ORBFE_OK) rc = orbfe_detect_batch(ctx, n_frames, stream);
+    if (rc == ORBFE_OK) rc = orbfe_describe_batch(ctx, n_frames, d_records, d_counts, soa, stream);
+    return rc;
+}
+
+int orbfe_extract_rgb(orbfe_ctx *ctx, const uint8_t *d_rgb, size_t pitch, size_t frame_stride, int n_frames,
+                      orbfe_keypoint *d_records, int32_t *d_counts, const orbfe_soa *soa, orbfe_stream_t stream)
+{
+    if (!ctx) return ORBFE_ERR_INVALID_ARG;
+    if (!d_records || !d_counts) CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "extract_rgb: null output");
+    int rc = orbfe_build_pyramid_rgb(ctx, d_rgb, pitch, frame_stride, n_frames, stream);
     if (rc == ORBFE_OK) rc = orbfe_detect_batch(ctx, n_frames, stream);
     if (rc == ORBFE_OK) rc = orbfe_describe_batch(ctx, n_frames, d_records, d_counts, soa, stream);
     return rc;

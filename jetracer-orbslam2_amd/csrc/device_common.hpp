@@ -66,6 +66,26 @@ __device__ inline void xcd_remap(int items, int n_frames, int *frame, int *item)
     }
 }
 
+// f1  RGB8 -> gray, src/cuda/cuda_RGB_to_Grayscale.cu:10-23: floor((B*0.07 + G*0.72 + R*0.21) + 0.5)
+// evaluated in double, left to right, without contraction (see oracle_rgb_to_grayscale).
+__device__ inline uint32_t rgb_to_gray1(uint32_t r, uint32_t g, uint32_t b)
+{
+    ORBFE_NO_CONTRACT
+    double t = (double)(float)b * 0.07;
+    t = t + (double)(float)g * 0.72;
+    t = t + (double)(float)r * 0.21;
+    return (uint32_t)(int)floor(t + 0.5);
+}
+// four pixels = 12 bytes R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3 -> one dword of gray
+__device__ inline uint32_t rgb4_to_gray4(uint32_t w0, uint32_t w1, uint32_t w2)
+{
+    const uint32_t g0 = rgb_to_gray1(w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u);
+    const uint32_t g1 = rgb_to_gray1(w0 >> 24, w1 & 255u, (w1 >> 8) & 255u);
+    const uint32_t g2 = rgb_to_gray1((w1 >> 16) & 255u, w1 >> 24, w2 & 255u);
+    const uint32_t g3 = rgb_to_gray1((w2 >> 8) & 255u, (w2 >> 16) & 255u, w2 >> 24);
+    return g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+}
+
 // Pixel accessors: px(row, col) -> value.  GlobalPx reads the image; LdsPatch reads a patch
 // that one wave staged in LDS (origin = image position of patch byte (0, 0)).
 struct GlobalPx {

@@ -28,6 +28,17 @@ void format_error(char *ctx_err, const char *fmt, ...)
     va_end(ap);
 }
 
+// f1  RGB8 -> gray (cuda_RGB_to_Grayscale.cu:10-23), one thread per pixel
+__global__ void rgb_to_gray_px_kernel(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, int cols,
+                                      int rows, int dst_pitch, int src_pitch)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= cols || y >= rows) return;
+    const uint8_t *p = src + (size_t)y * src_pitch + 3 * x;
+    dst[(size_t)y * dst_pitch + x] = (uint8_t)rgb_to_gray1(p[0], p[1], p[2]);
+}
+
 // ------------------------------------------------------------------------------------
 // a2  3x3 Gaussian with the reference's 32-column seams (gaussian_blur_3x3.cu:15-53)
 // One thread = one output pixel; rows 0, h-2, h-1 are written as 0 (Q1).
@@ -372,6 +383,16 @@ int orbfe_device_count(void)
 }
 
 int orbfe_load_pattern(void) { return ORBFE_OK; }
+
+int orbfe_rgb_to_grayscale(unsigned char *d_dst, const unsigned char *d_src, int cols, int rows, int dst_pitch,
+                           int src_pitch, orbfe_stream_t stream)
+{
+    ARG_CHECK(d_dst && d_src && cols > 0 && rows > 0 && dst_pitch >= cols && src_pitch >= 3 * cols);
+    dim3 block(64, 4), grid((cols + 63) / 64, (rows + 3) / 4);
+    hipLaunchKernelGGL(rgb_to_gray_px_kernel, grid, block, 0, S(stream), d_dst, d_src, cols, rows, dst_pitch,
+                       src_pitch);
+    return launch_status("rgb_to_grayscale");
+}
 
 int orbfe_gaussian_blur_3x3(unsigned char *d_blurred, int blurred_pitch,
                             const unsigned char *d_image, int image_pitch, int w, int h,

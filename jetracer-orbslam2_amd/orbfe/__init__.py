@@ -52,6 +52,7 @@ _SIGS = {
     "orbfe_version": (C.c_int, []),
     "orbfe_device_count": (C.c_int, []),
     "orbfe_load_pattern": (C.c_int, []),
+    "orbfe_rgb_to_grayscale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "orbfe_gaussian_blur_3x3": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                           C.c_int, C.c_void_p]),
     "orbfe_pyramid_create_levels": (C.c_int, [C.POINTER(PyramidLevel), C.c_int, C.c_void_p]),
@@ -84,6 +85,10 @@ _SIGS = {
                                    C.POINTER(C.c_size_t)]),
     "orbfe_build_pyramid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int,
                                       C.c_void_p]),
+    "orbfe_build_pyramid_rgb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int,
+                                          C.c_void_p]),
+    "orbfe_extract_rgb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int,
+                                    C.c_void_p, C.c_void_p, C.POINTER(Soa), C.c_void_p]),
     "orbfe_detect_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "orbfe_detect_batch_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "orbfe_export_cell_keys": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
@@ -199,6 +204,11 @@ class Context:
                 stream=0):
         check(lib().orbfe_extract(self.handle, d_gray, pitch, frame_stride, n_frames, d_records,
                                   d_counts, C.byref(soa) if soa is not None else None, stream),
+              self.handle)
+
+    def extract_rgb(self, d_rgb, pitch, frame_stride, n_frames, d_records, d_counts, soa=None, stream=0):
+        check(lib().orbfe_extract_rgb(self.handle, d_rgb, pitch, frame_stride, n_frames, d_records,
+                                      d_counts, C.byref(soa) if soa is not None else None, stream),
               self.handle)
 
     def match_batch(self, d_records, d_counts, n_frames, mode, window, max_distance, d_idx,

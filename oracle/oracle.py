@@ -96,6 +96,14 @@ def fast_is_corner(mask, arc):
     return int(lib().oracle_fast_is_corner(C.c_uint32(mask), arc))
 
 
+def rgb_to_grayscale(rgb):
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w, _ = rgb.shape
+    out = np.zeros((h, w), np.uint8)
+    lib().oracle_rgb_to_grayscale(_p(out), _p(rgb), w, h, w, 3 * w)
+    return out
+
+
 def gaussian_blur_3x3(img):
     img = np.ascontiguousarray(img, dtype=np.uint8)
     h, w = img.shape

@@ -28,6 +28,29 @@ void oracle_sincosf(float x, float *s, float *c) { orbfe_sincosf(x, s, c); }
 int oracle_has_arc(uint32_t mask, int arc) { return orbfe_has_arc(mask, arc); }
 
 /* ------------------------------------------------------------------------------------
+ * f1  kernel_rgb_to_grayscale     src/cuda/cuda_RGB_to_Grayscale.cu:10-23
+ * dst = floor((B*0.07 + G*0.72 + R*0.21) + 0.5): R, G, B are floats, the constants doubles, so
+ * the expression is evaluated in double, left to right.  Restated literally with separate
+ * IEEE multiplies and adds (no contraction, as everywhere in this build; nvcc's default
+ * -fmad=true may fuse some of them, which changes the result only when 7B+72G+21R is within
+ * rounding error of k + 1/2 -- unobservable here, hence unpinned like the trig functions).
+ * ------------------------------------------------------------------------------------ */
+void oracle_rgb_to_grayscale(uint8_t *dst, const uint8_t *src, int cols, int rows, int dst_pitch,
+                             int src_pitch)
+{
+    for (int y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++) {
+            float R = (float)src[(size_t)y * src_pitch + x * 3 + 0];
+            float G = (float)src[(size_t)y * src_pitch + x * 3 + 1];
+            float B = (float)src[(size_t)y * src_pitch + x * 3 + 2];
+            double t = (double)B * 0.07;
+            t = t + (double)G * 0.72;
+            t = t + (double)R * 0.21;
+            dst[(size_t)y * dst_pitch + x] = (uint8_t)floor(t + 0.5);
+        }
+}
+
+/* ------------------------------------------------------------------------------------
  * a2  gaussian_blur_3x3        src/cuda/gaussian_blur_3x3.cu:15-53 (kernel), :55-73 (host)
  * One 32-lane warp per 32 columns of one row; horizontal taps come from __shfl_up/_down
  * inside the warp, so lane 0 has no left and lane 31 no right neighbour and gets its own

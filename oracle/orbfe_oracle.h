@@ -49,6 +49,9 @@ typedef struct oracle_keypoint {
 } oracle_keypoint;
 
 /* ---- one function per reference kernel / host function ---- */
+/* "next" row f1: kernel_rgb_to_grayscale, src/cuda/cuda_RGB_to_Grayscale.cu:10-23 */
+void oracle_rgb_to_grayscale(uint8_t *dst, const uint8_t *src, int cols, int rows, int dst_pitch,
+                             int src_pitch);
 void oracle_gaussian_blur_3x3(uint8_t *blurred, int blurred_pitch, const uint8_t *image,
                               int image_pitch, int w, int h);
 void oracle_halfsample(const uint8_t *src, int src_pitch, uint8_t *dst, int dst_pitch,

@@ -512,3 +512,54 @@ def test_tile_sharded_detection_merges_exactly(gpu, oracle_mod, w, h, levels, sh
     assert n == ref["count"] and n > ctx.K // 2
     assert rec.cpu().numpy().view(orbfe.KEYPOINT_DTYPE)[:n].tobytes() == ref["records"].tobytes()
     assert min(nonempty) > 0 and max(nonempty) < n, "every shard contributes, none sees everything"
+
+
+# ------------------------------------------------------------------ f1: RGB8 -> gray
+def _rgb_frame(w, h, seed):
+    rng = np.random.default_rng(seed)
+    rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    # make sure the exact-tie triples 7B + 72G + 21R == 50 (mod 100) are well represented
+    rgb[0, : min(w, 64)] = [[r, 50, (50 - 21 * r - 72 * 50) * 43 % 100] for r in range(min(w, 64))]
+    return rgb
+
+
+@pytest.mark.parametrize("w,h,extra", [(640, 480, 0), (37, 19, 5), (848, 480, 4)])
+def test_rgb_to_grayscale_stage(gpu, oracle_mod, w, h, extra):
+    torch, orbfe = gpu
+    rgb = _rgb_frame(w, h, 5)
+    ref = oracle_mod.rgb_to_grayscale(rgb)
+    buf = np.full((h, 3 * w + extra), 0x33, np.uint8)
+    buf[:, :3 * w] = rgb.reshape(h, 3 * w)
+    d_src = dev(torch, buf)
+    d_dst = torch.full((h, w + 3), 0x44, dtype=torch.uint8, device="cuda")
+    orbfe.check(orbfe.lib().orbfe_rgb_to_grayscale(d_dst.data_ptr(), d_src.data_ptr(), w, h, w + 3,
+                                                   3 * w + extra, stream(torch)))
+    got = d_dst.cpu().numpy()
+    np.testing.assert_array_equal(got[:, :w], ref)
+    assert (got[:, w:] == 0x44).all()
+
+
+@pytest.mark.parametrize("w,h,levels", [(640, 480, 8), (100, 72, 3)])
+def test_extract_rgb_fused(gpu, oracle_mod, w, h, levels):
+    """RGB input: the conversion is fused into the pyramid kernel; result == oracle gray -> extract."""
+    torch, orbfe = gpu
+    n = 3
+    gray_scene = [synth.frame(w, h, 20 + i, "rects", **synth.DENSE) for i in range(n)]
+    rng = np.random.default_rng(9)
+    rgb = np.stack([np.stack([g, np.roll(g, 1, 1), 255 - g], -1) for g in gray_scene])  # three unlike channels
+    rgb = (rgb.astype(np.int16) + rng.integers(-2, 3, rgb.shape)).clip(0, 255).astype(np.uint8)
+    cfg = dict(levels=levels, cell=8, min_arc=9, max_features=500)
+    ctx = orbfe.Context(w, h, max_batch=n, **cfg)
+    d_in = dev(torch, rgb)
+    rec = torch.zeros(n * ctx.cap * 52, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(n, dtype=torch.int32, device="cuda")
+    ctx.extract_rgb(d_in.data_ptr(), 3 * w, 3 * w * h, n, rec.data_ptr(), cnt.data_ptr(), None, stream(torch))
+    torch.cuda.synchronize()
+    records = rec.cpu().numpy().view(orbfe.KEYPOINT_DTYPE).reshape(n, ctx.cap)
+    ocfg = oracle_mod.make_config(w, h, **cfg)
+    for f in range(n):
+        gray = oracle_mod.rgb_to_grayscale(rgb[f])
+        ref = oracle_mod.extract_frame(gray, ocfg, want_pyramid=True)
+        np.testing.assert_array_equal(ctx.read_level(0, f), ref["pyramid"][0])
+        assert int(cnt[f]) == ref["count"] > 50
+        assert records[f, :ref["count"]].tobytes() == ref["records"].tobytes()

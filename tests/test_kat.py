@@ -281,3 +281,24 @@ def test_top_n_selection_rule(oracle_mod):
     np.testing.assert_array_equal(np.flatnonzero(top["angle"] != 0) <= keep.max(), True)
     np.testing.assert_array_equal(top["records"]["score"], full["score"][keep])
     np.testing.assert_array_equal(top["records"]["x"], full["pos"][keep, 0])
+
+
+def test_rgb_to_grayscale_literal_double(oracle_mod):
+    """f1: floor((B*0.07 + G*0.72 + R*0.21) + 0.5) in double, left to right, no contraction.
+    It equals the exactly rounded value (7B + 72G + 21R + 50) // 100 except on some exact ties
+    (7B + 72G + 21R == 50 mod 100), where the binary constants decide -- that is the reference's
+    arithmetic, not a bug of the restatement."""
+    r, g, b = np.meshgrid(np.arange(256), np.arange(0, 256, 5), np.arange(256), indexing="ij")
+    rgb = np.stack([r, g, b], -1).reshape(256, -1, 3).astype(np.uint8)
+    got = oracle_mod.rgb_to_grayscale(rgb).astype(np.int64)
+    r, g, b = [rgb[..., i].astype(np.int64) for i in range(3)]
+    s = 7 * b + 72 * g + 21 * r
+    exact = (s + 50) // 100
+    diff = got != exact
+    assert (np.abs(got - exact) <= 1).all()
+    assert (s[diff] % 100 == 50).all(), "only exact ties may differ from round-half-up"
+    assert 0 < diff.sum() < (s % 100 == 50).sum()
+    # numpy evaluates the same IEEE double expression: bit-for-bit agreement
+    ref = np.floor((b.astype(np.float64) * 0.07 + g.astype(np.float64) * 0.72) + r.astype(np.float64) * 0.21 + 0.5)
+    np.testing.assert_array_equal(got, ref.astype(np.int64))
+    assert oracle_mod.rgb_to_grayscale(np.full((2, 2, 3), 255, np.uint8)).max() == 255
