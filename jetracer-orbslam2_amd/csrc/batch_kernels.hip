@@ -627,25 +627,43 @@ describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__re
         // dword i of the patch = (row i / kDw, column dword i % kDw); i advances by 64 per trip,
         // so (row, dword) advance by (64 / kDw, 64 % kDw) with one carry: no divisions
         int r = lane / kDw, q = lane - r * kDw;
+        // interior keypoints (the patch touches no excluded row / column): plain copies
+        const bool inner = oy > 0 && oy + kRows <= g.H && ax > 0 && ax + 4 * kDw <= g.W; // uniform
+        if (inner) {
+            uint32_t off = (uint32_t)(__mul24(oy + r, P) + ax + 4 * q);
+            const uint32_t dstep = (uint32_t)((64 / kDw) * P + 4 * (64 % kDw)); // offset step per trip
 #pragma unroll
-        for (int i0 = 0; i0 < kPatch; i0 += 64) {
-            const int i = i0 + lane;
-            const int gy = oy + r, gx = ax + 4 * q;
-            uint32_t v = 0;
-            // pixels the moments exclude (row <= 0, row >= H, column <= 0, column >= W) are
-            // staged as 0; the descriptor never samples them (17-px guard band)
-            if (i < kPatch && gy > 0 && gy < g.H && gx >= 0 && gx < g.W) {
-                v = *reinterpret_cast<const uint32_t *>(img + (uint32_t)(__mul24(gy, P) + gx));
-                if (gx == 0) v &= 0xFFFFFF00u;
-                const int nv = g.W - gx; // valid bytes in this dword
-                if (nv < 4) v &= (1u << (8 * nv)) - 1u;
+            for (int i0 = 0; i0 < kPatch; i0 += 64) {
+                const int i = i0 + lane;
+                if (i0 + 64 <= kPatch || i < kPatch) sp[i] = *reinterpret_cast<const uint32_t *>(img + off);
+                off += dstep;
+                q += 64 % kDw;
+                if (q >= kDw) { // carry into the next row
+                    q -= kDw;
+                    off += (uint32_t)(P - 4 * kDw);
+                }
             }
-            if (i < kPatch) sp[i] = v;
-            r += 64 / kDw;
-            q += 64 % kDw;
-            if (q >= kDw) {
-                q -= kDw;
-                r += 1;
+        } else {
+#pragma unroll
+            for (int i0 = 0; i0 < kPatch; i0 += 64) {
+                const int i = i0 + lane;
+                const int gy = oy + r, gx = ax + 4 * q;
+                uint32_t v = 0;
+                // pixels the moments exclude (row <= 0, row >= H, column <= 0, column >= W) are
+                // staged as 0; the descriptor never samples them (17-px guard band)
+                if (i < kPatch && gy > 0 && gy < g.H && gx >= 0 && gx < g.W) {
+                    v = *reinterpret_cast<const uint32_t *>(img + (uint32_t)(__mul24(gy, P) + gx));
+                    if (gx == 0) v &= 0xFFFFFF00u;
+                    const int nv = g.W - gx; // valid bytes in this dword
+                    if (nv < 4) v &= (1u << (8 * nv)) - 1u;
+                }
+                if (i < kPatch) sp[i] = v;
+                r += 64 / kDw;
+                q += 64 % kDw;
+                if (q >= kDw) {
+                    q -= kDw;
+                    r += 1;
+                }
             }
         }
     }

@@ -147,22 +147,40 @@ __device__ inline void patch_moments(const Px &px, int w, int h, int kx, int ky,
 // time (rows <= 0 or >= h, columns <= 0 or >= w: exactly the tests of orb.cu:98,112,119), so
 // no per-sample test is left: per row one LDS byte read, one select on the disc chord, two
 // adds; m10 takes its dx factor once at the end.  `centre` points at the keypoint's byte.
+// 64-bit lane mask of the lanes whose column lies inside the disc chord of row dy:
+// lane = column (0..30) + 32 * half, |column - 15| <= u[dy].  A compile-time constant, so the
+// chord test costs one v_cndmask with an SGPR-pair condition instead of a compare per row.
+__host__ __device__ constexpr uint64_t chord_mask(int dy)
+{
+    constexpr int u[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 7, 5, 0};
+    uint64_t m = 0;
+    for (int lane = 0; lane < 64; lane++) {
+        const int col = lane & 31;
+        const int adx = col > 15 ? col - 15 : 15 - col;
+        if (col < 31 && adx <= u[dy]) m |= 1ull << lane;
+    }
+    return m;
+}
+
 __device__ inline void patch_moments_staged(const uint8_t *centre, int pitch_bytes, int lane,
                                             int *m10_out, int *m01_out)
 {
-    constexpr int kU[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 7, 5, 0};
     int col = lane & 31;
     const bool idle = col == 31;
     col = idle ? 30 : col;
-    const int dx = col - 15, adx = dx < 0 ? -dx : dx;
+    const int dx = col - 15;
     const int step = (lane >> 5) ? pitch_bytes : -pitch_bytes; // half 1 walks down, half 0 up
     const uint8_t *p = centre + dx;
     int s = (lane >> 5) ? 0 : (int)p[0]; // centre row belongs to half 0
     int sy = 0;
 #pragma unroll
     for (int dy = 1; dy < 16; dy++) {
+        constexpr uint64_t kM[16] = {chord_mask(0),  chord_mask(1),  chord_mask(2),  chord_mask(3),
+                                     chord_mask(4),  chord_mask(5),  chord_mask(6),  chord_mask(7),
+                                     chord_mask(8),  chord_mask(9),  chord_mask(10), chord_mask(11),
+                                     chord_mask(12), chord_mask(13), chord_mask(14), chord_mask(15)};
         int v = p[dy * step];
-        v = adx <= kU[dy] ? v : 0;
+        asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(v) : "v"(v), "s"(kM[dy])); // v = lane in chord ? v : 0
         s += v;
         sy += dy * v;
     }
