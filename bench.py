@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--mode", choices=sorted(MODES), default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--stage-iters", type=int, default=10)
+    ap.add_argument("--stage-iters", type=int, default=10, help="(unused; kept for old command lines)")
     args = ap.parse_args()
 
     import torch
@@ -146,16 +146,30 @@ def main():
     pending = [None, None]
     step_no = [0]
 
-    def step():
+    stage_events = []  # per timed step: 5 events bracketing pyramid | detect | describe | match
+
+    def step(record=False):
         b = step_no[0] & 1
         step_no[0] += 1
         if pending[b] is not None:  # the gather that last read this buffer must be done
             pending[b].wait()
             pending[b] = None
         r, c = recs[b], cnts[b]
-        ctx.extract(frames.data_ptr(), w, w * h, B, r.data_ptr(), c.data_ptr(), None, s)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if record else None
+        # orbfe_extract == build_pyramid + detect_batch + describe_batch; issued separately so
+        # that HIP events on this stream can time each stage inside the timed region
+        if ev: ev[0].record()
+        ctx.build_pyramid(frames.data_ptr(), w, w * h, B, s)
+        if ev: ev[1].record()
+        ctx.detect_batch(B, s)
+        if ev: ev[2].record()
+        ctx.describe_batch(B, r.data_ptr(), c.data_ptr(), None, s)
+        if ev: ev[3].record()
         ctx.match_batch(r.data_ptr(), c.data_ptr(), B, mm["mode"], mm["window"], mm["max_distance"],
                         idx.data_ptr(), dst.data_ptr(), s)
+        if ev:
+            ev[4].record()
+            stage_events.append(ev)
         if world > 1:
             pending[b] = gather_keypoints_async(r, c, gather_out[b] if gather_out else None, dst=0)
 
@@ -177,7 +191,7 @@ def main():
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        step(record=True)
     sync()
     elapsed = time.perf_counter() - t0
     counts = cnt.cpu().numpy().astype(np.int64)
@@ -193,26 +207,16 @@ def main():
     else:
         kp_total, pairs_total = kp_local, pairs_local
 
-    # ---- per-stage device time, HIP events on the stream the kernels run on ----------
-    def timed(fn, iters):
-        fn()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / iters  # ms
-
+    # ---- per-stage device time: HIP events recorded on the kernels' stream inside the timed
+    #      region (averaged over the K timed steps)
     out = None
     if rank == 0:
-        it = args.stage_iters
-        ms_pyr = timed(lambda: ctx.build_pyramid(frames.data_ptr(), w, w * h, B, s), it)
-        ms_det = timed(lambda: ctx.detect_batch(B, s), it)
-        ms_desc = timed(lambda: ctx.describe_batch(B, rec.data_ptr(), cnt.data_ptr(), None, s), it)
-        ms_match = timed(lambda: ctx.match_batch(rec.data_ptr(), cnt.data_ptr(), B, mm["mode"], mm["window"],
-                                                 mm["max_distance"], idx.data_ptr(), dst.data_ptr(), s), it)
+        names = ("pyramid", "detect", "describe", "match")
+        ms = {k: 0.0 for k in names}
+        for ev in stage_events:
+            for i, k in enumerate(names):
+                ms[k] += ev[i].elapsed_time(ev[i + 1])
+        ms_pyr, ms_det, ms_desc, ms_match = (ms[k] / max(len(stage_events), 1) for k in names)
         detect_levels = sum(1 for l in range(m["cfg"]["levels"]) if (m["cfg"]["cell"] >> l) > 0
                             and (w >> l) > 0 and (h >> l) > 0)
         k_out = kp_local / B

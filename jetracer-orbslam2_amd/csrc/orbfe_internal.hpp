@@ -118,39 +118,6 @@ __host__ __device__ constexpr int ring_dy(int i)
          : i == 12 ? 0 : i == 13 ? 1 : i == 14 ? 2 : 3;
 }
 
-// Integer FAST score of the pixel at p (any address space), rows `pitch` apart.
-// Semantics of src/cuda/fast.cu:176-255 for an integer threshold t: darker <=> v < c - t,
-// brighter <=> v > c + t; corner <=> dark or bright mask holds a cyclic run >= arc;
-// score = max over the two labels of sum(|v - c| - t) on ALL pixels with that label.
-// The two opposite-pair prechecks (:98-124) only skip work, they never change a result
-// for arc >= 9 (a 9-run on a 16-ring covers at least one pixel of every opposite pair).
-template <typename PixelPtr>
-__device__ inline int fast_score_int(PixelPtr p, int pitch, int t, int arc)
-{
-    const int c = p[0];
-    const int lo = c - t, hi = c + t;
-    {
-        int a = p[-3], b = p[3];
-        if (a >= lo && a <= hi && b >= lo && b <= hi) return 0;
-        a = p[3 * pitch];
-        b = p[-3 * pitch];
-        if (a >= lo && a <= hi && b >= lo && b <= hi) return 0;
-    }
-    uint32_t dark = 0, bright = 0;
-    int sd = 0, sb = 0;
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const int v = p[ring_dy(i) * pitch + ring_dx(i)];
-        const bool d = v < lo, b = v > hi;
-        dark |= (uint32_t)d << i;
-        bright |= (uint32_t)b << i;
-        sd += d ? (lo - v) : 0;
-        sb += b ? (v - hi) : 0;
-    }
-    if (!(orbfe_has_arc(dark, arc) | orbfe_has_arc(bright, arc))) return 0;
-    return sd > sb ? sd : sb;
-}
-
 // ---- context -----------------------------------------------------------------------
 constexpr int kMaxLevels = 16;
 constexpr int kTileW = 64, kTileH = 32; // detection tile (pixels of one level)
