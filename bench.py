@@ -117,8 +117,16 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # ORBFE_BENCH_SHARE_GPU=1 (rehearsal on a 1-GPU box only): every rank uses cuda:0 and the
+        # collectives go over gloo, because RCCL refuses two ranks on one device
+        share = os.environ.get("ORBFE_BENCH_SHARE_GPU") == "1"
+        if share:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
