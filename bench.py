@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--mode", choices=sorted(MODES), default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rgb", action="store_true",
+                    help="feed interleaved RGB8 frames (SURVEY.md 8f-1): the gray conversion is fused into "
+                         "the pyramid kernel; not the BASELINE metric (its configs are grayscale)")
     ap.add_argument("--stage-iters", type=int, default=10, help="(unused; kept for old command lines)")
     args = ap.parse_args()
 
@@ -138,6 +141,9 @@ def main():
     n_distinct = min(16, B)
     base = synth.frames(w, h, n_distinct, first_index=1000 * rank, kind="rects", **synth.DENSE)
     frames = torch.from_numpy(base).to(dev)[torch.arange(B, device=dev) % n_distinct].contiguous()
+    if args.rgb:  # R = G = B = gray scene +- a channel-dependent offset: corners survive the conversion
+        off = torch.tensor([3, 0, -3], dtype=torch.int16, device=dev)
+        frames = (frames.to(torch.int16).unsqueeze(-1) + off).clamp(0, 255).to(torch.uint8).contiguous()
     # records / counts are double-buffered: the gather of step i (RCCL, asynchronous) overlaps
     # the kernels of step i + 1, which write the other buffer
     recs = [torch.zeros(B * ctx.cap * 52, dtype=torch.uint8, device=dev) for _ in range(2)]
@@ -167,7 +173,11 @@ def main():
         # orbfe_extract == build_pyramid + detect_batch + describe_batch; issued separately so
         # that HIP events on this stream can time each stage inside the timed region
         if ev: ev[0].record()
-        ctx.build_pyramid(frames.data_ptr(), w, w * h, B, s)
+        if args.rgb:
+            orbfe.check(orbfe.lib().orbfe_build_pyramid_rgb(ctx.handle, frames.data_ptr(), 3 * w, 3 * w * h, B, s),
+                        ctx.handle)
+        else:
+            ctx.build_pyramid(frames.data_ptr(), w, w * h, B, s)
         if ev: ev[1].record()
         ctx.detect_batch(B, s)
         if ev: ev[2].record()
@@ -261,7 +271,8 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": m["workload"], "frames_per_gpu_per_step": B,
+            "config": {"workload": m["workload"] + (" [RGB8 input, conversion fused]" if args.rgb else ""),
+                       "frames_per_gpu_per_step": B,
                        "frames_per_step": B * world, "keypoints_per_frame": k_out,
                        "collective": "async gather of 52-byte keypoint records to rank 0, overlapped with the "
                                      "next step" if world > 1 else "none"},
