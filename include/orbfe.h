@@ -135,6 +135,30 @@ int orbfe_match_keypoints(const float *d_pos_prev, const uint32_t *d_descriptors
                           int32_t *d_match_idx, int32_t *d_num_matched,
                           orbfe_stream_t stream);
 
+/* rs2_intrinsics (librealsense2 rs_types.h) as the reference's kernels read it
+ * (src/cuda/cuda-align.cu:57-112): same field order and meaning. */
+typedef struct orbfe_intrinsics {
+    int32_t width, height;
+    float ppx, ppy, fx, fy;
+    int32_t model; /* rs2_distortion: 0 none, 1 modified Brown-Conrady, 2 inverse Brown-Conrady, 3 f-theta, 4 Brown-Conrady */
+    float coeffs[5];
+} orbfe_intrinsics;
+
+/* keypoint_pixel_to_point, src/cuda/cuda-align.cuh (kernel cuda-align.cu:282-364), SURVEY.md 8f-2,
+ * the step right after the path: keep keypoints with aligned depth > 1 and score > 1, compact
+ * them and deproject to 3-D (3 doubles per point).  Differences: `intrin` is a HOST pointer (read
+ * at call time); the compacted order is by keypoint index (the reference's atomics give an
+ * arbitrary order); *d_valid_keypoints_num is written by the kernel, nothing is copied to the host.
+ * fix_depth_index = 0 reproduces the reference's depth lookup depth[int(y+.5) * W + int(y+.5)]
+ * (it uses y for the column, cuda-align.cu:332; needs height <= width); 1 uses int(x+.5).
+ * Forward-distorted models (1, 3) cannot be deprojected (the reference asserts): UNSUPPORTED. */
+int orbfe_keypoint_pixel_to_point(const uint32_t *d_aligned_depth, const orbfe_intrinsics *intrin,
+                                  int image_width, int image_height, float *d_pos_out,
+                                  const float *d_pos_in, const float *d_score, double *d_points,
+                                  uint32_t *d_descriptors_out, const uint32_t *d_descriptors_in,
+                                  int keypoints_num, int32_t *d_valid_keypoints_num,
+                                  int fix_depth_index, orbfe_stream_t stream);
+
 /* EXT: brute-force 256-bit Hamming matcher.  For every descriptor i of A the
  * lexicographic minimum (distance, index) over B; window < 0 disables the position gate
  * (then d_posA/d_posB may be NULL); matches with distance > max_distance give -1/-1. */

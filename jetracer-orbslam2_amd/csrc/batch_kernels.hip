@@ -465,25 +465,6 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
 // cell; max_features = N keeps the N best by (score desc, cell asc) (EXT ii).  Output is in
 // cell order either way, so it is deterministic.  Also fills the optional SoA view.
 // ------------------------------------------------------------------------------------
-__device__ inline int block_excl_scan(bool flag, int *s_wave, int *total)
-{
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint64_t m = __ballot(flag);
-    const int pre = (int)__popcll(m & ((1ull << lane) - 1ull));
-    __syncthreads();
-    if (lane == 0) s_wave[wv] = (int)__popcll(m);
-    __syncthreads();
-    int off = 0, tot = 0;
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const int v = s_wave[u];
-        off += (u < wv) ? v : 0;
-        tot += v;
-    }
-    *total = tot;
-    return off + pre;
-}
-
 __global__ void __launch_bounds__(256)
 select_kernel(DeviceGeom g, const uint32_t *__restrict__ cellkey, uint4 *__restrict__ sel,
               int32_t *__restrict__ selcount, int32_t *__restrict__ counts_out, orbfe_soa soa)

@@ -37,6 +37,27 @@ __device__ inline int wave_incl_scan_i32(int v)
     return v;
 }
 
+// Exclusive prefix count of `flag` over a 256-thread block (all threads must call it); *total =
+// number of set flags.  s_wave: 4 ints of LDS.
+__device__ inline int block_excl_scan(bool flag, int *s_wave, int *total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint64_t m = __ballot(flag);
+    const int pre = (int)__popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads();
+    if (lane == 0) s_wave[wv] = (int)__popcll(m);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int v = s_wave[u];
+        off += (u < wv) ? v : 0;
+        tot += v;
+    }
+    *total = tot;
+    return off + pre;
+}
+
 // Orientation patch half-widths, floor(sqrtf(225 - dy*dy) + 0.5) for dy = 0..15
 // (src/cuda/orb.cu:106; dy = 15 gives 0).
 static __constant__ int8_t c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 7, 5, 0};

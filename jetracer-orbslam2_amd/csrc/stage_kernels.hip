@@ -231,6 +231,65 @@ __global__ void calc_orb_kernel(const float *__restrict__ d_angle, const float *
 }
 
 // ------------------------------------------------------------------------------------
+// f2  keypoint filter + ordered compaction + deprojection (cuda-align.cu:85-112, :282-364).
+// One workgroup walks the keypoints in chunks of 256 with a running offset, so the output order
+// is the keypoint order.  f64 arithmetic as written in the reference, no contraction.
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+keypoint_pixel_to_point_kernel(const uint32_t *__restrict__ depth_img, orbfe_intrinsics K, int W,
+                               float *__restrict__ pos_out, const float *__restrict__ pos_in,
+                               const float *__restrict__ score_in, double *__restrict__ points,
+                               uint32_t *__restrict__ desc_out, const uint32_t *__restrict__ desc_in, int n,
+                               int32_t *__restrict__ n_valid, int fix_col)
+{
+    ORBFE_NO_CONTRACT
+    __shared__ int s_wave[4];
+    int base = 0;
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int idx = i0 + threadIdx.x;
+        bool ok = false;
+        float px = 0.f, py = 0.f;
+        int depth = 0;
+        if (idx < n) {
+            px = pos_in[2 * idx];
+            py = pos_in[2 * idx + 1];
+            const int row = (int)((double)py + 0.5);
+            const int col = fix_col ? (int)((double)px + 0.5) : (int)((double)py + 0.5);
+            depth = (int)depth_img[(size_t)row * W + col];
+            ok = depth > 1 && score_in[idx] > 1.0f;
+        }
+        int total;
+        const int slot = base + block_excl_scan(ok, s_wave, &total);
+        if (ok) {
+            double x = (double)((px - K.ppx) / K.fx);
+            double y = (double)((py - K.ppy) / K.fy);
+            if (K.model == 2) {
+                const double c0 = K.coeffs[0], c1 = K.coeffs[1], c2 = K.coeffs[2], c3 = K.coeffs[3], c4 = K.coeffs[4];
+                const double r2 = x * x + y * y;
+                double f = 1 + c0 * r2;
+                f = f + c1 * r2 * r2;
+                f = f + c4 * r2 * r2 * r2;
+                double ux = x * f + 2 * c2 * x * y;
+                ux = ux + c3 * (r2 + 2 * x * x);
+                double uy = y * f + 2 * c3 * x * y;
+                uy = uy + c2 * (r2 + 2 * y * y);
+                x = ux;
+                y = uy;
+            }
+            const double dd = (double)(float)depth;
+            points[3 * (size_t)slot + 0] = dd * x;
+            points[3 * (size_t)slot + 1] = dd * y;
+            points[3 * (size_t)slot + 2] = dd;
+            desc_out[slot] = desc_in[idx];
+            pos_out[2 * slot] = px;
+            pos_out[2 * slot + 1] = py;
+        }
+        base += total;
+    }
+    if (threadIdx.x == 0) *n_valid = base;
+}
+
+// ------------------------------------------------------------------------------------
 // a11  reference matcher (post_processing.cu:92-200).  Thread i = prev keypoint i; its
 // "tid" in the reference's 32-thread block is i & 31.  Curr keypoints are staged in LDS in
 // tiles of 32; inside a tile of m entries thread tid visits j = (s + tid) % m, s = 0..m-1,
@@ -527,6 +586,27 @@ int orbfe_match_keypoints(const float *d_pos_prev, const uint32_t *d_desc_prev, 
                        d_pos_prev, d_desc_prev, n_prev, d_pos_curr, d_desc_curr, n_curr,
                        (float)max_px, max_ham, d_match_idx, d_num_matched);
     return launch_status("match_keypoints");
+}
+
+int orbfe_keypoint_pixel_to_point(const uint32_t *d_aligned_depth, const orbfe_intrinsics *intrin, int image_width,
+                                  int image_height, float *d_pos_out, const float *d_pos_in, const float *d_score,
+                                  double *d_points, uint32_t *d_descriptors_out, const uint32_t *d_descriptors_in,
+                                  int keypoints_num, int32_t *d_valid_keypoints_num, int fix_depth_index,
+                                  orbfe_stream_t stream)
+{
+    ARG_CHECK(intrin && d_valid_keypoints_num && image_width > 0 && image_height > 0 && keypoints_num >= 0);
+    if (intrin->model == 1 || intrin->model == 3) {
+        set_thread_error("keypoint_pixel_to_point: cannot deproject a forward-distorted image (model %d)",
+                         intrin->model);
+        return ORBFE_ERR_UNSUPPORTED;
+    }
+    ARG_CHECK(fix_depth_index || image_height <= image_width); // the reference's index uses y as the column
+    ARG_CHECK(keypoints_num == 0 || (d_aligned_depth && d_pos_out && d_pos_in && d_score && d_points &&
+                                      d_descriptors_out && d_descriptors_in));
+    hipLaunchKernelGGL(keypoint_pixel_to_point_kernel, dim3(1), dim3(256), 0, S(stream), d_aligned_depth, *intrin,
+                       image_width, d_pos_out, d_pos_in, d_score, d_points, d_descriptors_out, d_descriptors_in,
+                       keypoints_num, d_valid_keypoints_num, fix_depth_index ? 1 : 0);
+    return launch_status("keypoint_pixel_to_point");
 }
 
 int orbfe_match256(const unsigned char *d_descA, const float *d_posA, int nA,

@@ -43,6 +43,11 @@ class Config(C.Structure):
                 ("max_batch", C.c_int32), ("device", C.c_int32)]
 
 
+class Intrinsics(C.Structure):  # orbfe_intrinsics == rs2_intrinsics
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("ppx", C.c_float), ("ppy", C.c_float),
+                ("fx", C.c_float), ("fy", C.c_float), ("model", C.c_int32), ("coeffs", C.c_float * 5)]
+
+
 class Soa(C.Structure):
     _fields_ = [("d_pos", C.c_void_p), ("d_score", C.c_void_p), ("d_level", C.c_void_p),
                 ("d_angle", C.c_void_p), ("d_desc", C.c_void_p), ("d_desc32", C.c_void_p)]
@@ -71,6 +76,9 @@ _SIGS = {
     "orbfe_match_keypoints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                         C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),
+    "orbfe_keypoint_pixel_to_point": (C.c_int, [C.c_void_p, C.POINTER(Intrinsics), C.c_int, C.c_int, C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "orbfe_match256": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                  C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "orbfe_default_config": (None, [C.POINTER(Config), C.c_int, C.c_int]),

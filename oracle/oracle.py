@@ -182,6 +182,26 @@ def calc_orb(angle, pos, img, angle_in_radians=0):
     return desc, d32
 
 
+class Intrinsics(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("ppx", C.c_float), ("ppy", C.c_float),
+                ("fx", C.c_float), ("fy", C.c_float), ("model", C.c_int32), ("coeffs", C.c_float * 5)]
+
+
+def keypoint_pixel_to_point(depth, intrin, pos, score, desc, fix_depth_index=0):
+    depth = np.ascontiguousarray(depth, dtype=np.uint32)
+    pos = np.ascontiguousarray(pos, dtype=np.float32).reshape(-1, 2)
+    score = np.ascontiguousarray(score, dtype=np.float32)
+    desc = np.ascontiguousarray(desc, dtype=np.uint32)
+    h, w = depth.shape
+    n = pos.shape[0]
+    pos_out = np.zeros((max(n, 1), 2), np.float32)
+    pts = np.zeros((max(n, 1), 3), np.float64)
+    dout = np.zeros(max(n, 1), np.uint32)
+    cnt = lib().oracle_keypoint_pixel_to_point(_p(depth), C.byref(intrin), w, h, _p(pos_out), _p(pos), _p(score),
+                                               _p(pts), _p(dout), _p(desc), n, fix_depth_index)
+    return pos_out[:cnt], pts[:cnt], dout[:cnt], cnt
+
+
 def match_keypoints(pos_prev, desc_prev, pos_curr, desc_curr, max_px=2, max_ham=4):
     pos_prev = np.ascontiguousarray(pos_prev, dtype=np.float32).reshape(-1, 2)
     pos_curr = np.ascontiguousarray(pos_curr, dtype=np.float32).reshape(-1, 2)

@@ -530,6 +530,60 @@ int oracle_match_keypoints(const float *pos_prev, const uint32_t *desc_prev, int
     return matched;
 }
 
+/* ------------------------------------------------------------------------------------
+ * f2  kernel_keypoint_pixel_to_point    src/cuda/cuda-align.cu:282-364
+ *     deproject_pixel_to_point_double   src/cuda/cuda-align.cu:85-112
+ * Keep keypoints with depth > 1 and score > 1.0f; deproject in double.  The pixel offsets
+ * (pixel - pp) / f are FLOAT operations (float operands) widened afterwards; the distortion
+ * polynomial is double with float coefficients, evaluated left to right without contraction.
+ * The depth lookup uses int(pos.y + 0.5) for BOTH row and column (:332, a reference bug kept in
+ * parity mode).  Decision: compaction is by ascending keypoint index (the reference's two-level
+ * atomicAdd gives an arbitrary order).  Returns the number of valid keypoints.
+ * ------------------------------------------------------------------------------------ */
+int oracle_keypoint_pixel_to_point(const uint32_t *aligned_depth, const oracle_intrinsics *intrin,
+                                   int image_width, int image_height, float *pos_out,
+                                   const float *pos_in, const float *score_in, double *points,
+                                   uint32_t *desc_out, const uint32_t *desc_in, int n,
+                                   int fix_depth_index)
+{
+    int count = 0;
+    (void)image_height;
+    for (int idx = 0; idx < n; idx++) {
+        const float px = pos_in[2 * idx], py = pos_in[2 * idx + 1];
+        const float score = score_in[idx];
+        const int row = (int)((double)py + 0.5);
+        const int col = fix_depth_index ? (int)((double)px + 0.5) : (int)((double)py + 0.5);
+        const int depth = (int)aligned_depth[(size_t)row * image_width + col];
+        if (!(depth > 1 && score > 1.0f)) continue;
+        const float fdepth = (float)depth;
+        double x = (double)((px - intrin->ppx) / intrin->fx);
+        double y = (double)((py - intrin->ppy) / intrin->fy);
+        if (intrin->model == 2) { /* RS2_DISTORTION_INVERSE_BROWN_CONRADY */
+            const double c0 = intrin->coeffs[0], c1 = intrin->coeffs[1], c2 = intrin->coeffs[2],
+                         c3 = intrin->coeffs[3], c4 = intrin->coeffs[4];
+            double r2 = x * x + y * y;
+            double f = 1 + c0 * r2;
+            f = f + c1 * r2 * r2;
+            f = f + c4 * r2 * r2 * r2;
+            double ux = x * f + 2 * c2 * x * y;
+            ux = ux + c3 * (r2 + 2 * x * x);
+            double uy = y * f + 2 * c3 * x * y;
+            uy = uy + c2 * (r2 + 2 * y * y);
+            x = ux;
+            y = uy;
+        }
+        const double depth_d = (double)fdepth;
+        points[3 * count + 0] = depth_d * x;
+        points[3 * count + 1] = depth_d * y;
+        points[3 * count + 2] = depth_d;
+        desc_out[count] = desc_in[idx];
+        pos_out[2 * count] = px;
+        pos_out[2 * count + 1] = py;
+        count++;
+    }
+    return count;
+}
+
 /* EXT C.9: brute-force 256-bit Hamming, lexicographic (dist, idx) minimum. */
 void oracle_match256(const uint8_t *descA, const float *posA, int nA, const uint8_t *descB,
                      const float *posB, int nB, int window, int max_dist, int32_t *idx,

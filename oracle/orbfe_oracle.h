@@ -70,6 +70,18 @@ void oracle_compute_fast_angle(float *angle, const float *pos, const float *scor
                                const uint8_t *img, int pitch, int w, int h, int n);
 void oracle_calc_orb(const float *angle, const float *pos, uint8_t *desc_tmp, uint32_t *desc32,
                      const uint8_t *img, int pitch, int w, int h, int n, int angle_in_radians);
+/* f2: kernel_keypoint_pixel_to_point + deproject_pixel_to_point_double, cuda-align.cu:85-112, :282-364 */
+typedef struct oracle_intrinsics {
+    int32_t width, height;
+    float ppx, ppy, fx, fy;
+    int32_t model;
+    float coeffs[5];
+} oracle_intrinsics;
+int oracle_keypoint_pixel_to_point(const uint32_t *aligned_depth, const oracle_intrinsics *intrin,
+                                   int image_width, int image_height, float *pos_out,
+                                   const float *pos_in, const float *score, double *points,
+                                   uint32_t *desc_out, const uint32_t *desc_in, int n,
+                                   int fix_depth_index);
 int oracle_match_keypoints(const float *pos_prev, const uint32_t *desc_prev, int n_prev,
                            const float *pos_curr, const uint32_t *desc_curr, int n_curr,
                            int max_px, int max_ham, int32_t *match_idx /*[n_prev], -1 = none*/);

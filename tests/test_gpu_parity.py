@@ -563,3 +563,48 @@ def test_extract_rgb_fused(gpu, oracle_mod, w, h, levels):
         np.testing.assert_array_equal(ctx.read_level(0, f), ref["pyramid"][0])
         assert int(cnt[f]) == ref["count"] > 50
         assert records[f, :ref["count"]].tobytes() == ref["records"].tobytes()
+
+
+# ------------------------------------------------------------------ f2: keypoint filter + deprojection
+@pytest.mark.parametrize("model,fix", [(0, 0), (2, 0), (4, 1), (2, 1)])
+@pytest.mark.parametrize("n", [0, 1, 300, 405, 1000])
+def test_keypoint_pixel_to_point(gpu, oracle_mod, model, fix, n):
+    torch, orbfe = gpu
+    w, h = 848, 480
+    rng = np.random.default_rng(n * 10 + model + fix)
+    depth = rng.integers(0, 5000, (h, w)).astype(np.uint32)
+    depth[rng.random((h, w)) < 0.3] = 0            # holes
+    depth[rng.random((h, w)) < 0.05] = 1           # depth == 1 is rejected too (depth > 1)
+    pos = np.stack([rng.integers(0, w, n), rng.integers(0, h, n)], 1).astype(np.float32)
+    score = rng.choice([0.0, 1.0, 2.0, 57.0], n).astype(np.float32)
+    desc = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+    coeffs = (C.c_float * 5)(0.12, -0.25, 0.001, -0.0007, 0.09)
+    ok = oracle_mod.Intrinsics(w, h, 423.6, 241.3, 610.5, 609.8, model, coeffs)
+    gk = orbfe.Intrinsics(w, h, 423.6, 241.3, 610.5, 609.8, model, coeffs)
+    rpos, rpts, rdesc, rcnt = oracle_mod.keypoint_pixel_to_point(depth, ok, pos, score, desc, fix)
+    z = lambda a, dt: dev(torch, a if a.size else np.zeros(4, dt))
+    d_depth, d_pos, d_score, d_desc = dev(torch, depth.view(np.int32)), z(pos, np.float32), z(score, np.float32), z(desc.view(np.int32), np.int32)
+    o_pos = torch.full((max(n, 1), 2), -1.0, device="cuda")
+    o_pts = torch.full((max(n, 1), 3), -1.0, dtype=torch.float64, device="cuda")
+    o_desc = torch.full((max(n, 1),), -1, dtype=torch.int32, device="cuda")
+    o_n = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+    orbfe.check(orbfe.lib().orbfe_keypoint_pixel_to_point(
+        d_depth.data_ptr(), C.byref(gk), w, h, o_pos.data_ptr(), d_pos.data_ptr(), d_score.data_ptr(),
+        o_pts.data_ptr(), o_desc.data_ptr(), d_desc.data_ptr(), n, o_n.data_ptr(), fix, stream(torch)))
+    cnt = int(o_n.cpu()[0])
+    assert cnt == rcnt
+    np.testing.assert_array_equal(o_pos.cpu().numpy()[:cnt], rpos)
+    np.testing.assert_array_equal(o_pts.cpu().numpy()[:cnt].view(np.uint64), rpts.view(np.uint64))  # f64 bit patterns
+    np.testing.assert_array_equal(o_desc.cpu().numpy()[:cnt].view(np.uint32), rdesc)
+    if n >= 300:
+        assert 0 < cnt < n
+
+
+def test_keypoint_pixel_to_point_rejects_forward_distortion(gpu):
+    torch, orbfe = gpu
+    k = orbfe.Intrinsics(64, 48, 32, 24, 50, 50, 1, (C.c_float * 5)())
+    one = torch.zeros(8, dtype=torch.int32, device="cuda")
+    rc = orbfe.lib().orbfe_keypoint_pixel_to_point(one.data_ptr(), C.byref(k), 64, 48, one.data_ptr(), one.data_ptr(),
+                                                   one.data_ptr(), one.data_ptr(), one.data_ptr(), one.data_ptr(), 1,
+                                                   one.data_ptr(), 1, 0)
+    assert rc == orbfe.ERR_UNSUPPORTED

@@ -302,3 +302,22 @@ def test_rgb_to_grayscale_literal_double(oracle_mod):
     ref = np.floor((b.astype(np.float64) * 0.07 + g.astype(np.float64) * 0.72) + r.astype(np.float64) * 0.21 + 0.5)
     np.testing.assert_array_equal(got, ref.astype(np.int64))
     assert oracle_mod.rgb_to_grayscale(np.full((2, 2, 3), 255, np.uint8)).max() == 255
+
+
+def test_deprojection_known_answers(oracle_mod):
+    """f2: pinhole deprojection point = depth * ((px - ppx) / fx, (py - ppy) / fy, 1); the filter
+    keeps depth > 1 and score > 1; the reference's depth lookup uses y for row AND column."""
+    import ctypes as C
+    w, h = 64, 48
+    depth = np.zeros((h, w), np.uint32)
+    depth[10, 10] = 2000      # what the reference reads for a keypoint at y = 10 (any x)
+    depth[10, 40] = 3000      # what a correct lookup reads for (x, y) = (40, 10)
+    k = oracle_mod.Intrinsics(w, h, 32.0, 24.0, 50.0, 40.0, 0, (C.c_float * 5)())
+    pos = np.array([[40, 10], [5, 5], [40, 10]], np.float32)
+    score = np.array([9, 9, 1], np.float32)            # third: score == 1 is rejected
+    desc = np.array([11, 22, 33], np.uint32)
+    p, pts, d, n = oracle_mod.keypoint_pixel_to_point(depth, k, pos, score, desc, 0)
+    assert n == 1 and d[0] == 11
+    np.testing.assert_allclose(pts[0], [2000 * (40 - 32) / 50, 2000 * (10 - 24) / 40, 2000], rtol=1e-6)
+    p, pts, d, n = oracle_mod.keypoint_pixel_to_point(depth, k, pos, score, desc, 1)
+    assert n == 1 and pts[0][2] == 3000
