@@ -608,3 +608,33 @@ def test_keypoint_pixel_to_point_rejects_forward_distortion(gpu):
                                                    one.data_ptr(), one.data_ptr(), one.data_ptr(), one.data_ptr(), 1,
                                                    one.data_ptr(), 1, 0)
     assert rc == orbfe.ERR_UNSUPPORTED
+
+
+# ------------------------------------------------------------------ randomised configurations
+def test_fuzz_random_configurations(gpu, oracle_mod):
+    """40 seeded random (size, levels, cell, arc, threshold, budget, angle mode, scene) draws: the
+    batch path must equal the oracle record for record, whatever the geometry (odd sizes take the
+    unfused pyramid kernels, W % 4 == 0 the fused one; tiles, cells and levels rarely align)."""
+    torch, orbfe = gpu
+    import os
+    rng = np.random.default_rng(int(os.environ.get("ORBFE_FUZZ_SEED", "20261004")))
+    kinds = ["rects", "dense", "uniform", "checker"]
+    total = 0
+    for trial in range(int(os.environ.get("ORBFE_FUZZ_TRIALS", "40"))):
+        w = int(rng.integers(40, 400))
+        h = int(rng.integers(40, 300))
+        if trial % 3 == 0:
+            w -= w % 4
+        cfg = dict(levels=int(rng.integers(1, 9)), cell=int(rng.choice([8, 16, 32, 64])),
+                   min_arc=int(rng.integers(9, 13)), fast_threshold=int(rng.integers(3, 40)),
+                   max_features=int(rng.choice([0, 0, 7, 50, 400])), angle_in_radians=int(rng.integers(0, 2)))
+        n = int(rng.integers(1, 4))
+        frames = np.stack([synth.frame(w, h, int(rng.integers(0, 10 ** 6)), "uniform") if k == "uniform" else
+                           FRAMES[k](w, h) for k in rng.choice(kinds, n)])
+        ctx, rec, cnt, soa = _run_extract(torch, orbfe, frames, **cfg)
+        try:
+            total += _check_extract(oracle_mod, ctx, frames, rec, cnt, soa, **cfg)
+        except AssertionError as e:
+            raise AssertionError("trial %d: %dx%d %r: %s" % (trial, w, h, cfg, e))
+        ctx.close()
+    assert total > 2000
