@@ -837,25 +837,28 @@ match_batch_256_kernel(const Desc8 *__restrict__ mdesc, const float2 *__restrict
     uint32_t best = 0xFFFFFFFFu;
     // distance key of one candidate whose descriptor is in SGPRs
     auto key_of = [&](const u32x8 &b, int j) {
-        uint32_t dist = 0;
+        uint32_t dist, key;
+        {
+            const uint32_t x = a.w[0] ^ b[0];
+            asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(dist) : "v"(x)); // first word: accumulate into literal 0
+        }
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
+        for (int k = 1; k < 8; k++) {
             const uint32_t x = a.w[k] ^ b[k];
             asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(dist) : "v"(x));
         }
-        uint32_t key = (dist << 16) | (uint32_t)j;
+        asm("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(key) : "v"(dist), "s"(j)); // dist << 16 | j, j wave-uniform
         if (WINDOW) {
             const float2 pb = Bp[j];
             if (fabsf(pa.x - pb.x) > win || fabsf(pa.y - pb.y) > win) key = 0xFFFFFFFFu;
         }
         return key;
     };
+    auto umin = [](uint32_t x, uint32_t y) { return x < y ? x : y; };
     auto group_min = [&](const u32x8 (&g)[4], int j) {
-        uint32_t k0 = key_of(g[0], j), k1 = key_of(g[1], j + 1), k2 = key_of(g[2], j + 2), k3 = key_of(g[3], j + 3);
-        k0 = k0 < k1 ? k0 : k1;
-        k2 = k2 < k3 ? k2 : k3;
-        k0 = k0 < k2 ? k0 : k2;
-        best = k0 < best ? k0 : best;
+        const uint32_t k0 = key_of(g[0], j), k1 = key_of(g[1], j + 1), k2 = key_of(g[2], j + 2), k3 = key_of(g[3], j + 3);
+        best = umin(umin(best, k0), k1); // -> v_min3_u32
+        best = umin(umin(best, k2), k3);
     };
     // Hand-made scalar-load pipeline.  SMEM returns out of order, so the only usable wait is
     // lgkmcnt(0); hipcc places a group's s_loads right before its wait, which exposes the full
