@@ -26,6 +26,9 @@ def gpu():
     import torch
     import orbfe
     assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    if not os.path.exists(orbfe.LIB_PATH) or not os.path.exists(os.path.join(ROOT, "examples", "buildstream_port")):
+        import __graft_entry__  # clean checkout: build the HIP library, the oracle and the example
+        __graft_entry__.build()
     orbfe.lib()  # raises if liborbfe.so is not built
     assert orbfe.lib().orbfe_device_count() >= 1
     return torch, orbfe

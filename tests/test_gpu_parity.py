@@ -638,3 +638,42 @@ def test_fuzz_random_configurations(gpu, oracle_mod):
             raise AssertionError("trial %d: %dx%d %r: %s" % (trial, w, h, cfg, e))
         ctx.close()
     assert total > 2000
+
+
+# ------------------------------------------------------------------ the C++ port of buildStream
+def test_cpp_buildstream_port(gpu, oracle_mod, tmp_path):
+    """examples/buildstream_port.cpp issues the reference's per-frame call sequence
+    (buildStream.cpp:399-466) through compat/jetracer_compat.hpp, i.e. with the reference's own
+    function names; its feature grid, angles and descriptors must equal the oracle's."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "buildstream_port")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    w, h, levels = 848, 480, 5
+    g = synth.frame(w, h, 31, "rects", **synth.DENSE)
+    rgb = np.stack([g, np.roll(g, 2, 0), np.roll(g, 3, 1)], -1)
+    fin, fout = str(tmp_path / "rgb.bin"), str(tmp_path / "out.bin")
+    rgb.tofile(fin)
+    subprocess.check_call([exe, str(w), str(h), str(levels), fin, fout])
+    k = oracle_mod.num_cells(w, h)
+    raw = np.fromfile(fout, np.uint8)
+    assert raw.size == k * (16 + 4 + 32 + 4)
+    grid = raw[:16 * k].view(np.float32)
+    angle = raw[16 * k:20 * k].view(np.float32)
+    desc = raw[20 * k:52 * k].reshape(k, 32)
+    d32 = raw[52 * k:].view(np.uint32)
+    # oracle, stage by stage as the reference calls them (all K cells get an angle: the stage
+    # API has no score input, exactly like compute_fast_angle)
+    gray = oracle_mod.rgb_to_grayscale(rgb)
+    imgs, resps, _ = _response_pyramid(oracle_mod, gray, levels)
+    rpos, rscore, rlevel = oracle_mod.grid_nms(resps, 32)
+    rangle = oracle_mod.compute_fast_angle(rpos, None, imgs[0])
+    rdesc, rd32 = oracle_mod.calc_orb(rangle, rpos, imgs[0])
+    np.testing.assert_array_equal(bits(grid[:2 * k].reshape(k, 2)), bits(rpos))
+    np.testing.assert_array_equal(bits(grid[2 * k:3 * k]), bits(rscore))
+    np.testing.assert_array_equal(grid[3 * k:].view(np.int32), rlevel)
+    np.testing.assert_array_equal(bits(angle), bits(rangle))
+    np.testing.assert_array_equal(desc, rdesc)
+    np.testing.assert_array_equal(d32, rd32)
+    assert (rscore > 0).sum() > k // 2
