@@ -111,6 +111,9 @@ def main():
     import torch
     import torch.distributed as dist
     import orbfe
+    if not os.path.exists(orbfe.LIB_PATH) and int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        import __graft_entry__  # clean checkout: compile the HIP library first (hipcc, gfx950)
+        __graft_entry__.build()
     from orbfe import synth
     from orbfe.dist import gather_keypoints_async
 
