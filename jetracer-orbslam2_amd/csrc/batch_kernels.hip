@@ -465,13 +465,17 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
 // cell; max_features = N keeps the N best by (score desc, cell asc) (EXT ii).  Output is in
 // cell order either way, so it is deterministic.  Also fills the optional SoA view.
 // ------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+constexpr int kSelThreads = 1024; // one workgroup per frame: wide, because the kernel is latency-bound
+constexpr int kSelWaves = kSelThreads / 64;
+
+__global__ void __launch_bounds__(kSelThreads)
 select_kernel(DeviceGeom g, const uint32_t *__restrict__ cellkey, uint4 *__restrict__ sel,
               int32_t *__restrict__ selcount, int32_t *__restrict__ counts_out, orbfe_soa soa)
 {
+    constexpr int kBinsPer = 4096 / kSelThreads; // score bins owned by one thread
     __shared__ uint32_t s_hist[4096];
-    __shared__ int s_wave[4];
-    __shared__ int s_tot[256];
+    __shared__ int s_wave[kSelWaves];
+    __shared__ int s_tot[kSelThreads];
     __shared__ int s_thr, s_quota;
     const int f = blockIdx.x, tid = threadIdx.x;
     const uint32_t *keys = cellkey + (size_t)f * g.K;
@@ -481,24 +485,30 @@ select_kernel(DeviceGeom g, const uint32_t *__restrict__ cellkey, uint4 *__restr
         s_quota = 0;        // ... plus the first s_quota cells with score == s_thr
     }
     if (g.max_features > 0) {
-        for (int i = tid; i < 4096; i += 256) s_hist[i] = 0u;
+        for (int i = tid; i < 4096; i += kSelThreads) s_hist[i] = 0u;
         __syncthreads();
-        for (int k = tid; k < g.K; k += 256) {
+        for (int k = tid; k < g.K; k += kSelThreads) {
             const uint32_t s = keys[k] >> 15;
             if (s) atomicAdd(&s_hist[s], 1u);
         }
         __syncthreads();
-        // thread t owns bins 16t .. 16t+15; `above` = how many scores lie in higher bins
+        // thread t owns bins kBinsPer * t ...; `above` = how many scores lie in higher bins
         int mine = 0;
-        for (int b = 0; b < 16; b++) mine += (int)s_hist[16 * tid + b];
+        for (int b = 0; b < kBinsPer; b++) mine += (int)s_hist[kBinsPer * tid + b];
         s_tot[tid] = mine;
         __syncthreads();
-        int above = 0;
-        for (int u = tid + 1; u < 256; u++) above += s_tot[u];
-        for (int b = 15; b >= 0; b--) {
-            const int n = (int)s_hist[16 * tid + b];
+        // suffix sum over threads: in-place Hillis-Steele on s_tot (log2(1024) = 10 steps)
+        for (int d = 1; d < kSelThreads; d <<= 1) {
+            const int v = tid + d < kSelThreads ? s_tot[tid + d] : 0;
+            __syncthreads();
+            s_tot[tid] += v;
+            __syncthreads();
+        }
+        int above = s_tot[tid] - mine; // scores in bins owned by higher threads
+        for (int b = kBinsPer - 1; b >= 0; b--) {
+            const int n = (int)s_hist[kBinsPer * tid + b];
             if (above < g.max_features && above + n >= g.max_features && n > 0) {
-                s_thr = 16 * tid + b;
+                s_thr = kBinsPer * tid + b;
                 s_quota = g.max_features - above;
             }
             above += n;
@@ -508,17 +518,17 @@ select_kernel(DeviceGeom g, const uint32_t *__restrict__ cellkey, uint4 *__restr
     const int thr = s_thr, quota = s_quota;
 
     int n_sel = 0, n_tie = 0;
-    for (int base = 0; base < g.K; base += 256) {
+    for (int base = 0; base < g.K; base += kSelThreads) {
         const int k = base + tid;
         const bool in = k < g.K;
         const uint32_t key = in ? keys[k] : 0u;
         const int score = (int)(key >> 15);
         const bool tie = in && thr > 0 && score == thr;
         int tie_tot;
-        const int tie_rank = block_excl_scan(tie, s_wave, &tie_tot);
+        const int tie_rank = block_excl_scan<kSelWaves>(tie, s_wave, &tie_tot);
         const bool keep = in && score > 0 && (score > thr || (tie && n_tie + tie_rank < quota));
         int keep_tot;
-        const int slot = block_excl_scan(keep, s_wave, &keep_tot);
+        const int slot = block_excl_scan<kSelWaves>(keep, s_wave, &keep_tot);
         int s = 0, l = 0, x = 0, y = 0;
         const bool want_soa = soa.d_pos || soa.d_score || soa.d_level || soa.d_angle || soa.d_desc || soa.d_desc32;
         if (keep || (in && want_soa)) nms_decode(key, k % g.cells_x, k / g.cells_x, g.cell, &s, &l, &x, &y);
@@ -1186,7 +1196,7 @@ int orbfe_describe_batch(orbfe_ctx *ctx, int n_frames, orbfe_keypoint *d_records
     orbfe_soa so = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (soa) so = *soa;
     ORBFE_HIP_TRY(ctx->err, hipSetDevice(ctx->cfg.device));
-    hipLaunchKernelGGL(select_kernel, dim3(n_frames), dim3(256), 0, S(stream), g, ctx->d_cellkey, ctx->d_sel,
+    hipLaunchKernelGGL(select_kernel, dim3(n_frames), dim3(kSelThreads), 0, S(stream), g, ctx->d_cellkey, ctx->d_sel,
                        ctx->d_selcount, d_counts, so);
     if (g.angle_in_radians)
         hipLaunchKernelGGL(describe_kernel<19>, dim3((g.cap + 4 * kKpw - 1) / (4 * kKpw), n_frames), dim3(256), 0,

@@ -37,8 +37,9 @@ __device__ inline int wave_incl_scan_i32(int v)
     return v;
 }
 
-// Exclusive prefix count of `flag` over a 256-thread block (all threads must call it); *total =
-// number of set flags.  s_wave: 4 ints of LDS.
+// Exclusive prefix count of `flag` over a block of NW waves (all threads must call it); *total =
+// number of set flags.  s_wave: NW ints of LDS.
+template <int NW = 4>
 __device__ inline int block_excl_scan(bool flag, int *s_wave, int *total)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -49,7 +50,7 @@ __device__ inline int block_excl_scan(bool flag, int *s_wave, int *total)
     __syncthreads();
     int off = 0, tot = 0;
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < NW; u++) {
         const int v = s_wave[u];
         off += (u < wv) ? v : 0;
         tot += v;
