@@ -215,7 +215,7 @@ pyramid_fused_kernel(DeviceGeom g, uint8_t *__restrict__ pyr, const uint8_t *__r
 }
 
 // ------------------------------------------------------------------------------------
-// a5 + a6 fused  FAST score + 3x3 NMS + per-cell maximum for one 64x32 tile of one level of
+// a5 + a6 fused  FAST score + 3x3 NMS + per-cell maximum for one 64x64 tile of one level of
 // one frame.  Most pixels are not corners, so the work is staged to keep the lanes busy:
 //   A  load the pixel tile (4-px halo: ring radius 3 + NMS radius 1) into LDS as dwords
 //   B  compass pre-test on 4 pixels per lane with packed-u16 min/max: a cyclic arc of >= 9
@@ -236,9 +236,9 @@ __device__ inline us2 ssub(us2 a, us2 b) { return __builtin_elementwise_sub_sat(
 __device__ inline us2 pmin(us2 a, us2 b) { return __builtin_elementwise_min(a, b); }
 __device__ inline us2 pmax(us2 a, us2 b) { return __builtin_elementwise_max(a, b); }
 
-constexpr int kPxW = kTileW + 8, kPxH = kTileH + 8; // 72 x 40 pixel tile
+constexpr int kPxW = kTileW + 8, kPxH = kTileH + 8; // 72 x 72 pixel tile
 constexpr int kPxDw = kPxW / 4;                      // 18 dwords per row
-constexpr int kScW = kTileW + 2, kScH = kTileH + 2; // 66 x 34 score tile (1-px halo)
+constexpr int kScW = kTileW + 2, kScH = kTileH + 2; // 66 x 66 score tile (1-px halo)
 constexpr int kScPitch = kScW + 2;                   // 68
 constexpr int kMaxLdsCells = (kTileW / 4) * (kTileH / 4);
 
@@ -307,10 +307,13 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
     __shared__ __attribute__((aligned(16))) uint16_t s_sc[kScH * kScPitch];
     // per-wave queues (wave w owns the tasks tid = 64 w + lane of every trip): the fill level
     // is a wave-uniform register, so compaction needs no atomics and no block barrier
-    constexpr int kTrips = (kScH * kPxDw + 255) / 256;  // task trips per wave
+    constexpr int kMainTrips = kTileH * 16 / 256;       // trips over the tile proper (16 groups per row)
+    constexpr int kTrips = kMainTrips + 1;              // + one trip for the halo ring
     constexpr int kQ1 = kTrips * 64 * 4;                // candidates a wave can produce
-    __shared__ uint16_t s_q1[4][kQ1];                   // (r << 7) | px
-    __shared__ uint16_t s_q2[4][kQ1];                   // positives among them
+    static_assert(32 + 2 * kScH <= 256, "halo trip must fit one block");
+    // (r << 7) | px.  The positives queue q2 lives IN PLACE in q1: its write index never passes
+    // the read index (positives so far <= candidates consumed), same wave, in-order LDS.
+    __shared__ uint16_t s_q1[4][kQ1];
     __shared__ uint32_t s_key[kMaxLdsCells];
 
     int f, tile_id;
@@ -340,23 +343,24 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
         for (int i = tid; i < ncx * ncy; i += 256) s_key[i] = 0u;
     __syncthreads();
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    uint16_t *q1 = s_q1[wv], *q2 = s_q2[wv];
+    uint16_t *q1 = s_q1[wv], *q2 = s_q1[wv];
 
     // ---- B: compass pre-test, 4 pixels per lane; score-tile row r <-> image y0 - 1 + r,
     //         pixel-tile column px <-> image x0 - 4 + px
     const uint32_t t2 = (uint32_t)g.threshold * 0x00010001u;
     const bool need3 = g.arc >= 12;
     int n1 = 0; // wave-uniform fill level of q1
-    // Task = one dword group q (pixels px = 4q .. 4q+3) of score row r.  Trips 0 and 1 cover the
-    // tile proper (rows 1..32, groups 1..16: 512 tasks, no division in the mapping); trip 2 the
-    // 1-pixel halo ring (rows 0 and 33, and the single pixels px = 3 / px = 68 of every row).
+    // Task = one dword group q (pixels px = 4q .. 4q+3) of score row r.  The first kMainTrips
+    // trips cover the tile proper (rows 1..kTileH, groups 1..16, 16 rows per trip: no division in
+    // the mapping); the last trip the 1-pixel halo ring (rows 0 and kScH-1, and the single pixels
+    // px = 3 / px = 68 of every row).
     // `inner` tiles (no image border inside the score tile) skip the per-pixel range tests.
-    const bool inner = x0 >= 4 && x0 + 64 < W - 3 && y0 >= 4 && y0 + 32 < H - 3;
+    const bool inner = x0 >= 4 && x0 + kTileW < W - 3 && y0 >= 4 && y0 + kTileH < H - 3;
     for (int trip = 0; trip < kTrips; trip++) {
         uint32_t flags = 0;
         int r, q;
         uint32_t mask = 0xFu; // pixels of the group that belong to the score tile
-        if (trip < 2) {
+        if (trip < kMainTrips) {
             q = (tid & 15) + 1;
             r = (tid >> 4) + 1 + 16 * trip;
         } else if (tid < 32) {

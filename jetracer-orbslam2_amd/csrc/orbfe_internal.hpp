@@ -120,7 +120,7 @@ __host__ __device__ constexpr int ring_dy(int i)
 
 // ---- context -----------------------------------------------------------------------
 constexpr int kMaxLevels = 16;
-constexpr int kTileW = 64, kTileH = 32; // detection tile (pixels of one level)
+constexpr int kTileW = 64, kTileH = 64; // detection tile (pixels of one level)
 
 struct LevelInfo {
     int w, h, pitch;
