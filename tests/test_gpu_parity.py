@@ -677,3 +677,32 @@ def test_cpp_buildstream_port(gpu, oracle_mod, tmp_path):
     np.testing.assert_array_equal(desc, rdesc)
     np.testing.assert_array_equal(d32, rd32)
     assert (rscore > 0).sum() > k // 2
+
+
+# ------------------------------------------------------------------ stream capture
+def test_calls_are_graph_capturable(gpu):
+    """No entry point allocates or synchronises, so a whole step can be captured into a HIP graph
+    (the caller may do that; the bench does not: replay measured slower than eager issue here)."""
+    torch, orbfe = gpu
+    w, h, n = 640, 480, 4
+    frames = dev(torch, synth.frames(w, h, n, 50, "rects", **synth.DENSE))
+    ctx = orbfe.Context(w, h, levels=8, cell=8, min_arc=9, max_features=2000, max_batch=n)
+    rec = torch.zeros(n * ctx.cap * 52, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(n, dtype=torch.int32, device="cuda")
+    idx = torch.zeros((n - 1) * ctx.cap, dtype=torch.int32, device="cuda")
+
+    def step(s):
+        ctx.extract(frames.data_ptr(), w, w * h, n, rec.data_ptr(), cnt.data_ptr(), None, s)
+        ctx.match_batch(rec.data_ptr(), cnt.data_ptr(), n, 1, -1, 256, idx.data_ptr(), None, s)
+
+    step(stream(torch))
+    torch.cuda.synchronize()
+    want = (rec.clone(), cnt.clone(), idx.clone())
+    rec.zero_(), cnt.zero_(), idx.zero_()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step(stream(torch))
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(rec, want[0]) and torch.equal(cnt, want[1]) and torch.equal(idx, want[2])
+    assert int(cnt.sum()) == n * 2000
