@@ -224,6 +224,19 @@ __device__ inline bool orb_border_zero(int lx, int ly, int w, int h, int radians
                    : (lx < 17 || lx > w - 17 || ly < 17 || ly > h - 17);
 }
 
+// Round-half-even of v (|v| < 2^22) plus an integer, in two full-rate instructions: adding
+// 1.5 * 2^23 makes the float's low mantissa bits the rounded integer (default rounding mode is
+// nearest-even, exactly what CUDA __float2int_rn / rintf do), so
+//     as_int(v + 12582912.0f) - 0x4B400000 == (int)rintf(v)
+// and the integer offset folds into the subtraction.  Bit-identical to orbfe_rn_int for this range
+// (the oracle keeps the rintf form; the parity tests compare the two on every descriptor).
+__device__ inline int rn_plus(float v, int add)
+{
+    ORBFE_NO_CONTRACT
+    const float r = v + 12582912.0f;
+    return (int)__float_as_uint(r) + (add - 0x4B400000);
+}
+
 // (a, b) = (cos, sin) of the steering angle (orb_steer below)
 template <typename Px>
 __device__ inline void orb_describe(const Px &px, int lx, int ly, float a, float b, int lane, uint64_t d[4])
@@ -235,8 +248,8 @@ __device__ inline void orb_describe(const Px &px, int lx, int ly, float a, float
         const float fpx = pt.x, fpy = pt.y, fqx = pt.z, fqy = pt.w;
         const float p1 = fpx * b, p2 = fpy * a, p3 = fpx * a, p4 = fpy * b;
         const float q1 = fqx * b, q2 = fqy * a, q3 = fqx * a, q4 = fqy * b;
-        const int prow = ly + orbfe_rn_int(p1 + p2), pcol = lx + orbfe_rn_int(p3 - p4);
-        const int qrow = ly + orbfe_rn_int(q1 + q2), qcol = lx + orbfe_rn_int(q3 - q4);
+        const int prow = rn_plus(p1 + p2, ly), pcol = rn_plus(p3 - p4, lx);
+        const int qrow = rn_plus(q1 + q2, ly), qcol = rn_plus(q3 - q4, lx);
         const int t0 = px(prow, pcol);
         const int t1 = px(qrow, qcol);
         d[r] = __ballot(t0 < t1);
