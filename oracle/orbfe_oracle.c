@@ -584,11 +584,43 @@ int oracle_keypoint_pixel_to_point(const uint32_t *aligned_depth, const oracle_i
     return count;
 }
 
+/* 256-bit Hamming distance as 4 x 64-bit popcounts; the hardware popcnt form is picked at run
+ * time so that the CPU baseline is a fair port wherever the library lands (same results). */
+static int ham256_generic(const uint8_t *a, const uint8_t *b)
+{
+    int d = 0;
+    for (int k = 0; k < 4; k++) {
+        uint64_t wa, wb;
+        memcpy(&wa, a + 8 * k, 8);
+        memcpy(&wb, b + 8 * k, 8);
+        d += __builtin_popcountll(wa ^ wb);
+    }
+    return d;
+}
+#if defined(__x86_64__)
+__attribute__((target("popcnt"))) static int ham256_popcnt(const uint8_t *a, const uint8_t *b)
+{
+    int d = 0;
+    for (int k = 0; k < 4; k++) {
+        uint64_t wa, wb;
+        memcpy(&wa, a + 8 * k, 8);
+        memcpy(&wb, b + 8 * k, 8);
+        d += __builtin_popcountll(wa ^ wb);
+    }
+    return d;
+}
+#endif
+
 /* EXT C.9: brute-force 256-bit Hamming, lexicographic (dist, idx) minimum. */
 void oracle_match256(const uint8_t *descA, const float *posA, int nA, const uint8_t *descB,
                      const float *posB, int nB, int window, int max_dist, int32_t *idx,
                      int32_t *dist)
 {
+    int (*ham)(const uint8_t *, const uint8_t *) = ham256_generic;
+#if defined(__x86_64__)
+    __builtin_cpu_init();
+    if (__builtin_cpu_supports("popcnt")) ham = ham256_popcnt;
+#endif
     for (int i = 0; i < nA; i++) {
         int best = 1 << 30, best_j = -1;
         for (int j = 0; j < nB; j++) {
@@ -597,9 +629,7 @@ void oracle_match256(const uint8_t *descA, const float *posA, int nA, const uint
                     fabsf(posA[2 * i + 1] - posB[2 * j + 1]) > (float)window)
                     continue;
             }
-            int d = 0;
-            for (int b = 0; b < 32; b++)
-                d += __builtin_popcount((unsigned)(descA[32 * i + b] ^ descB[32 * j + b]));
+            const int d = ham(descA + 32 * (size_t)i, descB + 32 * (size_t)j);
             if (d < best) {
                 best = d;
                 best_j = j;
