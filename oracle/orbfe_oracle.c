@@ -584,65 +584,65 @@ int oracle_keypoint_pixel_to_point(const uint32_t *aligned_depth, const oracle_i
     return count;
 }
 
-/* 256-bit Hamming distance as 4 x 64-bit popcounts; the hardware popcnt form is picked at run
- * time so that the CPU baseline is a fair port wherever the library lands (same results). */
-static int ham256_generic(const uint8_t *a, const uint8_t *b)
-{
-    int d = 0;
-    for (int k = 0; k < 4; k++) {
-        uint64_t wa, wb;
-        memcpy(&wa, a + 8 * k, 8);
-        memcpy(&wb, b + 8 * k, 8);
-        d += __builtin_popcountll(wa ^ wb);
+/* EXT C.9: brute-force 256-bit Hamming, lexicographic (dist, idx) minimum.
+ * 256 bits = 4 x 64-bit popcounts.  The loop is instantiated twice, once for the hardware popcnt
+ * instruction (picked at run time when the host has it) so that the CPU baseline is a fair port
+ * wherever the library lands; both give the same results. */
+#define ORACLE_MATCH256_BODY                                                                       \
+    for (int i = 0; i < nA; i++) {                                                                 \
+        int best = 1 << 30, best_j = -1;                                                           \
+        uint64_t wa[4];                                                                            \
+        memcpy(wa, descA + 32 * (size_t)i, 32);                                                    \
+        for (int j = 0; j < nB; j++) {                                                             \
+            if (window >= 0) {                                                                     \
+                if (fabsf(posA[2 * i] - posB[2 * j]) > (float)window ||                            \
+                    fabsf(posA[2 * i + 1] - posB[2 * j + 1]) > (float)window)                      \
+                    continue;                                                                      \
+            }                                                                                      \
+            uint64_t wb[4];                                                                        \
+            memcpy(wb, descB + 32 * (size_t)j, 32);                                                \
+            const int d = __builtin_popcountll(wa[0] ^ wb[0]) + __builtin_popcountll(wa[1] ^ wb[1]) + \
+                          __builtin_popcountll(wa[2] ^ wb[2]) + __builtin_popcountll(wa[3] ^ wb[3]);  \
+            if (d < best) {                                                                        \
+                best = d;                                                                          \
+                best_j = j;                                                                        \
+            }                                                                                      \
+        }                                                                                          \
+        if (best_j >= 0 && best <= max_dist) {                                                     \
+            idx[i] = best_j;                                                                       \
+            dist[i] = best;                                                                        \
+        } else {                                                                                   \
+            idx[i] = -1;                                                                           \
+            dist[i] = -1;                                                                          \
+        }                                                                                          \
     }
-    return d;
+
+static void match256_generic(const uint8_t *descA, const float *posA, int nA, const uint8_t *descB,
+                             const float *posB, int nB, int window, int max_dist, int32_t *idx, int32_t *dist)
+{
+    ORACLE_MATCH256_BODY
 }
 #if defined(__x86_64__)
-__attribute__((target("popcnt"))) static int ham256_popcnt(const uint8_t *a, const uint8_t *b)
+__attribute__((target("popcnt"))) static void match256_popcnt(const uint8_t *descA, const float *posA, int nA,
+                                                              const uint8_t *descB, const float *posB, int nB,
+                                                              int window, int max_dist, int32_t *idx, int32_t *dist)
 {
-    int d = 0;
-    for (int k = 0; k < 4; k++) {
-        uint64_t wa, wb;
-        memcpy(&wa, a + 8 * k, 8);
-        memcpy(&wb, b + 8 * k, 8);
-        d += __builtin_popcountll(wa ^ wb);
-    }
-    return d;
+    ORACLE_MATCH256_BODY
 }
 #endif
 
-/* EXT C.9: brute-force 256-bit Hamming, lexicographic (dist, idx) minimum. */
 void oracle_match256(const uint8_t *descA, const float *posA, int nA, const uint8_t *descB,
                      const float *posB, int nB, int window, int max_dist, int32_t *idx,
                      int32_t *dist)
 {
-    int (*ham)(const uint8_t *, const uint8_t *) = ham256_generic;
 #if defined(__x86_64__)
     __builtin_cpu_init();
-    if (__builtin_cpu_supports("popcnt")) ham = ham256_popcnt;
-#endif
-    for (int i = 0; i < nA; i++) {
-        int best = 1 << 30, best_j = -1;
-        for (int j = 0; j < nB; j++) {
-            if (window >= 0) {
-                if (fabsf(posA[2 * i] - posB[2 * j]) > (float)window ||
-                    fabsf(posA[2 * i + 1] - posB[2 * j + 1]) > (float)window)
-                    continue;
-            }
-            const int d = ham(descA + 32 * (size_t)i, descB + 32 * (size_t)j);
-            if (d < best) {
-                best = d;
-                best_j = j;
-            }
-        }
-        if (best_j >= 0 && best <= max_dist) {
-            idx[i] = best_j;
-            dist[i] = best;
-        } else {
-            idx[i] = -1;
-            dist[i] = -1;
-        }
+    if (__builtin_cpu_supports("popcnt")) {
+        match256_popcnt(descA, posA, nA, descB, posB, nB, window, max_dist, idx, dist);
+        return;
     }
+#endif
+    match256_generic(descA, posA, nA, descB, posB, nB, window, max_dist, idx, dist);
 }
 
 /* ------------------------------------------------------------------------------------
