@@ -326,16 +326,41 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
     const int tid = threadIdx.x, lane = tid & 63;
     const uint8_t *s_px = reinterpret_cast<const uint8_t *>(s_px32);
 
-    // ---- A: pixel tile as dwords (x0 - 4 is dword aligned; rows are 64-byte aligned)
-    for (int i = tid; i < kPxH * kPxDw; i += 256) {
-        const int r = i / kPxDw, q = i - r * kPxDw;
-        const int gy = y0 - 4 + r, gx = x0 - 4 + 4 * q;
-        uint32_t v = 0;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < P)
-            v = *reinterpret_cast<const uint32_t *>(img + (size_t)gy * P + gx);
-        s_px32[i] = v;
+    // ---- A: pixel tile as dwords (x0 - 4 is dword aligned; rows are 64-byte aligned).  Dword i of
+    //         the tile = (row i / 18, group i % 18); i advances by 256 per trip = 14 rows + 4 groups
+    //         with one carry, so there is no division; tiles that lie inside the image (with their
+    //         halo) skip the range tests.
+    {
+        const bool all_in = x0 >= 4 && x0 + kTileW + 4 <= P && y0 >= 4 && y0 + kTileH + 4 <= H; // uniform
+        int r = tid / kPxDw, q = tid - r * kPxDw;
+        uint32_t off = (uint32_t)(__mul24(y0 - 4 + r, P) + x0 - 4 + 4 * q); // wraps harmlessly when unused
+        const uint32_t dstep = (uint32_t)((256 / kPxDw) * P + 4 * (256 % kPxDw));
+#pragma unroll
+        for (int i0 = 0; i0 < kPxH * kPxDw; i0 += 256) {
+            const int i = i0 + tid;
+            if (i0 + 256 <= kPxH * kPxDw || i < kPxH * kPxDw) {
+                uint32_t v = 0;
+                if (all_in) {
+                    v = *reinterpret_cast<const uint32_t *>(img + off);
+                } else {
+                    const int gy = y0 - 4 + r, gx = x0 - 4 + 4 * q;
+                    if (gy >= 0 && gy < H && gx >= 0 && gx < P) v = *reinterpret_cast<const uint32_t *>(img + off);
+                }
+                s_px32[i] = v;
+            }
+            off += dstep;
+            r += 256 / kPxDw;
+            q += 256 % kPxDw;
+            if (q >= kPxDw) { // carry into the next row
+                q -= kPxDw;
+                r += 1;
+                off += (uint32_t)(P - 4 * kPxDw);
+            }
+        }
+        static_assert((kScH * kScPitch * 2) % 16 == 0, "score tile is zeroed with 16-byte stores");
+        for (int i = tid; i < kScH * kScPitch / 8; i += 256)
+            reinterpret_cast<uint4 *>(s_sc)[i] = make_uint4(0u, 0u, 0u, 0u);
     }
-    for (int i = tid; i < kScH * kScPitch / 2; i += 256) reinterpret_cast<uint32_t *>(s_sc)[i] = 0u;
     const int c = g.cell >> l, lc = ilog2(c);
     const bool lds_cells = c >= 4;
     const int ncx = kTileW / c > 0 ? kTileW / c : 1, ncy = kTileH / c > 0 ? kTileH / c : 1;
