@@ -706,3 +706,46 @@ def test_calls_are_graph_capturable(gpu):
     torch.cuda.synchronize()
     assert torch.equal(rec, want[0]) and torch.equal(cnt, want[1]) and torch.equal(idx, want[2])
     assert int(cnt.sum()) == n * 2000
+
+
+# ------------------------------------------------------------------ BASELINE configs[2]
+@pytest.mark.parametrize("mode,cfg,window,maxd", [
+    (0, dict(levels=1), 4, 4),                                      # the reference's live regime (K = 405)
+    (0, dict(levels=6), 4, 8),
+    (1, dict(levels=8, cell=8, min_arc=9, max_features=2000), -1, 256),
+    (1, dict(levels=8, cell=8, min_arc=9, max_features=2000, angle_in_radians=1), 6, 80),
+])
+def test_stereo_pair_848x480_extract_and_match(gpu, oracle_mod, mode, cfg, window, maxd):
+    """848x480 pair (right = left shifted by 3 px + noise): extract both frames, match left -> right;
+    records, match indices and distances equal the oracle's."""
+    torch, orbfe = gpu
+    w, h = 848, 480
+    left, right = synth.shifted_pair(w, h, 77, dx=3, dy=0, **synth.DENSE)
+    frames = np.stack([left, right])
+    ctx, rec, cnt, _ = _run_extract(torch, orbfe, frames, want_soa=False, **cfg)
+    ocfg = oracle_mod.make_config(w, h, levels=cfg.get("levels", 1), cell=cfg.get("cell", 32),
+                                  min_arc=cfg.get("min_arc", 12), max_features=cfg.get("max_features", 0),
+                                  angle_in_radians=cfg.get("angle_in_radians", 0))
+    refs = [oracle_mod.extract_frame(frames[f], ocfg)["records"] for f in range(2)]
+    for f in range(2):
+        assert cnt[f] == len(refs[f]) and rec[f, :cnt[f]].tobytes() == refs[f].tobytes()
+    d_rec, d_cnt = dev(torch, rec.view(np.uint8).reshape(-1)), dev(torch, cnt)
+    d_idx = torch.full((ctx.cap,), -7, dtype=torch.int32, device="cuda")
+    d_dist = torch.full((ctx.cap,), -7, dtype=torch.int32, device="cuda")
+    ctx.match_batch(d_rec.data_ptr(), d_cnt.data_ptr(), 2, mode, window, maxd, d_idx.data_ptr(), d_dist.data_ptr(),
+                    stream(torch))
+    a, b = refs
+    pa, pb = np.stack([a["x"], a["y"]], 1), np.stack([b["x"], b["y"]], 1)
+    if mode == 0:
+        comp = lambda d: ((d == 1).astype(np.uint32) << np.arange(32, dtype=np.uint32)).sum(1).astype(np.uint32)
+        ref_idx, _ = oracle_mod.match_keypoints(pa, comp(a["desc"]), pb, comp(b["desc"]), window, maxd)
+    else:
+        ref_idx, ref_dist = oracle_mod.match256(a["desc"], b["desc"], pa, pb, window, maxd)
+        np.testing.assert_array_equal(d_dist.cpu().numpy()[:cnt[0]], ref_dist)
+    np.testing.assert_array_equal(d_idx.cpu().numpy()[:cnt[0]], ref_idx)
+    assert (ref_idx >= 0).sum() > 5
+    if mode == 1 and window < 0:
+        # a 3-px shift: most left keypoints find their right counterpart 3 px to the right
+        m = ref_idx >= 0
+        dx = pb[ref_idx[m], 0] - pa[m, 0]
+        assert (np.abs(dx - 3) <= 1).mean() > 0.3
