@@ -650,12 +650,17 @@ describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__re
         // interior keypoints (the patch touches no excluded row / column): plain copies
         const bool inner = oy > 0 && oy + kRows <= g.H && ax > 0 && ax + 4 * kDw <= g.W; // uniform
         if (inner) {
+            // LDS-DMA: global_load_lds_dword writes lane L's dword to (uniform LDS base) + 4 L with
+            // no VGPR round trip and no ds_write; the base advances by 64 dwords per trip
             uint32_t off = (uint32_t)(__mul24(oy + r, P) + ax + 4 * q);
             const uint32_t dstep = (uint32_t)((64 / kDw) * P + 4 * (64 % kDw)); // offset step per trip
 #pragma unroll
             for (int i0 = 0; i0 < kPatch; i0 += 64) {
                 const int i = i0 + lane;
-                if (i0 + 64 <= kPatch || i < kPatch) sp[i] = *reinterpret_cast<const uint32_t *>(img + off);
+                if (i0 + 64 <= kPatch || i < kPatch)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(img + off),
+                        (__attribute__((address_space(3))) void *)(sp + i0), 4, 0, 0);
                 off += dstep;
                 q += 64 % kDw;
                 if (q >= kDw) { // carry into the next row
@@ -687,6 +692,9 @@ describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__re
             }
         }
     }
+    // LDS-DMA data is only ordered behind this wave's vmcnt: wait for every staged dword before
+    // the first LDS read (the compiler's own wait insertion does not cover it reliably)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // LDS ops of one wave are in order
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
