@@ -247,7 +247,7 @@ def main():
         c64 = counts.astype(np.int64)
         ab["match"] = float((40 * (c64[:-1] + c64[1:]) + 8 * c64[:-1]).sum()) / B if mm["mode"] == 1 else \
             float((12 * (c64[:-1] + c64[1:]) + 8 * c64[:-1]).sum()) / B
-        kernels = {"pyramid": "blur_batch_kernel+halfsample_batch_kernel", "detect": "detect_tile_kernel",
+        kernels = {"pyramid": "pyramid_fused_kernel", "detect": "detect_tile_kernel",
                    "describe": "select_kernel+describe_kernel",
                    "match": "match_gather_kernel+match_batch_256_kernel" if mm["mode"] == 1 else "match_batch_ref_kernel"}
         traffic_all = {}

@@ -1073,6 +1073,11 @@ int orbfe_create(const orbfe_config *cfg, orbfe_ctx **out)
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_selcount, B * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_mdesc, B * g.cap * 32);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_mpos, B * g.cap * 8);
+    ctx->cap_pad = (g.cap + 15) / 16 * 16;
+    if (g.cap <= kMmaMaxKeypoints) { // scratch of the matrix-core matcher
+        if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_mexp, B * ctx->cap_pad * 128);
+        if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_mkey, B * ctx->cap_pad * sizeof(float));
+    }
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_tiles, (tiles.size() + 1) * sizeof(TileDesc));
     if (e == hipSuccess && !tiles.empty())
         e = hipMemcpy(ctx->d_tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice);
@@ -1095,6 +1100,8 @@ void orbfe_destroy(orbfe_ctx *ctx)
     if (ctx->d_tiles) (void)hipFree(ctx->d_tiles);
     if (ctx->d_mdesc) (void)hipFree(ctx->d_mdesc);
     if (ctx->d_mpos) (void)hipFree(ctx->d_mpos);
+    if (ctx->d_mexp) (void)hipFree(ctx->d_mexp);
+    if (ctx->d_mkey) (void)hipFree(ctx->d_mkey);
     delete ctx;
 }
 
@@ -1288,6 +1295,13 @@ int orbfe_match_batch(orbfe_ctx *ctx, const orbfe_keypoint *d_records, const int
     else {
         if (n_frames > ctx->cfg.max_batch)
             CTX_FAIL(ctx, ORBFE_ERR_CAPACITY, "match_batch: n_frames %d > max_batch %d", n_frames, ctx->cfg.max_batch);
+        if (window < 0 && ctx->d_mexp) { // all candidates, <= 16384 per frame: matrix cores
+            const int capP = ctx->cap_pad;
+            launch_match_mfma(d_records, d_counts, n_frames, cap, capP, max_distance, ctx->d_mexp, ctx->d_mkey, d_idx,
+                              d_dist, S(stream));
+            CTX_LAUNCH_CHECK(ctx, "match_batch");
+            return ORBFE_OK;
+        }
         Desc8 *md = reinterpret_cast<Desc8 *>(ctx->d_mdesc);
         float2 *mp = reinterpret_cast<float2 *>(ctx->d_mpos);
         hipLaunchKernelGGL(match_gather_kernel, dim3((cap + 255) / 256, n_frames), block, 0, S(stream), d_records,

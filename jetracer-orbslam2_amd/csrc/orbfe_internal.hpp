@@ -145,6 +145,11 @@ struct DeviceGeom { // passed by value to kernels
     LevelInfo lv[kMaxLevels];
 };
 
+// match_mfma.hip: 256-bit brute-force matching of frames f-1 -> f on the matrix cores
+constexpr int kMmaMaxKeypoints = 16384;
+void launch_match_mfma(const orbfe_keypoint *d_records, const int32_t *d_counts, int n_frames, int cap, int capP,
+                       int max_dist, uint4 *mexp, float *mkey, int32_t *d_idx, int32_t *d_dist, hipStream_t stream);
+
 } // namespace orbfe
 
 struct orbfe_ctx {
@@ -156,6 +161,9 @@ struct orbfe_ctx {
     int32_t *d_selcount = nullptr;  // [max_batch]
     uint8_t *d_mdesc = nullptr;     // [max_batch][cap][32]  matcher scratch: dense descriptors
     uint8_t *d_mpos = nullptr;      // [max_batch][cap] float2 matcher scratch: positions
+    uint4 *d_mexp = nullptr;        // [max_batch][cap_pad][8]  MFMA matcher: descriptors as e2m1 fragments (cap <= 16384)
+    float *d_mkey = nullptr;        // [max_batch][cap_pad]     MFMA matcher: -(popcount * 16384 + index)
+    int cap_pad = 0;                // cap rounded up to 16
     orbfe::TileDesc *d_tiles = nullptr;
     int n_tiles = 0;
     char err[512] = {0};

@@ -456,6 +456,63 @@ def test_match_batch(gpu, oracle_mod, mode, window, maxd):
     assert n_matched > 10
 
 
+@pytest.mark.parametrize("w,h,kw", [(100, 70, dict(cell=8)),                       # cap 117: not a multiple of 16
+                                    (640, 480, dict(cell=32)),                     # cap 300
+                                    (640, 480, dict(cell=8, max_features=2000)),   # the bench regime
+                                    (640, 480, dict(cell=8))])                     # cap 4800: 38 row blocks
+@pytest.mark.parametrize("maxd", [256, 90, 0])
+def test_match_batch_256_crafted_records(gpu, oracle_mod, w, h, kw, maxd):
+    """The all-candidates 256-bit matcher (matrix-core path) on hand-made records: random,
+    duplicated, all-zero and all-one descriptors, ragged counts including 0 and 1, ties (the
+    lower index must win), every output slot beyond the count = -1."""
+    torch, orbfe = gpu
+    ctx = orbfe.Context(w, h, max_batch=8, **kw)
+    cap = ctx.cap
+    rng = np.random.default_rng(cap * 1000 + maxd)
+    counts = np.array([cap, 0, 5, cap, 1, cap - 1, min(cap, 37), cap], np.int32)
+    n = len(counts)
+    rec = np.zeros((n, cap), orbfe.KEYPOINT_DTYPE)
+    rec["desc"] = rng.integers(0, 256, (n, cap, 32), dtype=np.uint8)
+    rec["x"] = rng.uniform(0, w, (n, cap)).astype(np.float32)
+    rec["y"] = rng.uniform(0, h, (n, cap)).astype(np.float32)
+    # near-duplicates across consecutive frames so small distances exist, plus exact ties
+    for f in range(1, n):
+        m = min(counts[f - 1], counts[f])
+        if m < 4:
+            continue
+        src = rng.integers(0, counts[f - 1], m // 2)
+        dst = rng.integers(0, counts[f], m // 2)
+        d = rec["desc"][f - 1, src].copy()
+        flips = rng.integers(0, 40, len(src))
+        for k, nf in enumerate(flips):
+            for bit in rng.integers(0, 256, nf):
+                d[k, bit >> 3] ^= np.uint8(1 << (bit & 7))
+        rec["desc"][f, dst] = d
+        rec["desc"][f, dst[: len(dst) // 4]] = rec["desc"][f, dst[0]]  # ties: same descriptor at many indices
+    rec["desc"][3, : min(cap, 3)] = 0
+    rec["desc"][3, min(cap, 3): min(cap, 6)] = 255
+    rec["desc"][7, cap // 2] = 0
+    rec["desc"][7, cap - 1] = 255
+    d_rec = dev(torch, rec.view(np.uint8).reshape(-1))
+    d_cnt = dev(torch, counts)
+    d_idx = torch.full(((n - 1) * cap,), -7, dtype=torch.int32, device="cuda")
+    d_dist = torch.full(((n - 1) * cap,), -7, dtype=torch.int32, device="cuda")
+    ctx.match_batch(d_rec.data_ptr(), d_cnt.data_ptr(), n, 1, -1, maxd, d_idx.data_ptr(), d_dist.data_ptr(),
+                    stream(torch))
+    idx = d_idx.cpu().numpy().reshape(n - 1, cap)
+    dist = d_dist.cpu().numpy().reshape(n - 1, cap)
+    for p in range(n - 1):
+        A, B = rec[p, :counts[p]], rec[p + 1, :counts[p + 1]]
+        ref_idx, ref_dist = oracle_mod.match256(A["desc"], B["desc"], None, None, -1, maxd)
+        np.testing.assert_array_equal(idx[p, :counts[p]], ref_idx)
+        np.testing.assert_array_equal(dist[p, :counts[p]], ref_dist)
+        assert (idx[p, counts[p]:] == -1).all() and (dist[p, counts[p]:] == -1).all()
+    # d_dist may be NULL
+    d_idx2 = torch.full(((n - 1) * cap,), -7, dtype=torch.int32, device="cuda")
+    ctx.match_batch(d_rec.data_ptr(), d_cnt.data_ptr(), n, 1, -1, maxd, d_idx2.data_ptr(), None, stream(torch))
+    assert torch.equal(d_idx, d_idx2)
+
+
 # ------------------------------------------------------------------ full-size properties
 def test_full_size_batch_properties(gpu, oracle_mod):
     """BASELINE configs[1] at bench size (batch 256): size-independent properties.

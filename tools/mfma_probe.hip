@@ -1,0 +1,96 @@
+// Probe: does v_mfma_f32_16x16x128_f8f6f4 with fp4 (e2m1) operands compute exact binary dot
+// products with the fragment layout the matcher assumes, and how fast does it issue?
+//   hipcc --offload-arch=gfx950 -O3 -o tools/mfma_probe tools/mfma_probe.hip && tools/mfma_probe
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// 8 bits -> 8 nibbles, bit b -> nibble b = 0x2 (fp4 e2m1 1.0) or 0
+__device__ __host__ inline uint32_t spread8(uint32_t x) {
+    x &= 0xFF;
+    x = (x | (x << 12)) & 0x000F000Fu;
+    x = (x | (x << 6)) & 0x03030303u;
+    x = (x | (x << 3)) & 0x11111111u;
+    return x << 1;
+}
+
+template <int SCALE>
+__global__ void probe_kernel(const uint32_t* a_bits, const uint32_t* b_bits, float* out) {
+    // a_bits/b_bits: [16][8] words.  lane l: row/col l&15, chunk l>>4 -> word kstep*4 + chunk
+    int l = threadIdx.x;
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < 2; ++ks) {
+        uint32_t wa = a_bits[(l & 15) * 8 + ks * 4 + (l >> 4)];
+        uint32_t wb = b_bits[(l & 15) * 8 + ks * 4 + (l >> 4)];
+        v8i fa = {0, 0, 0, 0, 0, 0, 0, 0}, fb = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 4; ++i) {
+            fa[i] = (int)spread8(wa >> (8 * i));
+            fb[i] = (int)spread8(wb >> (8 * i));
+        }
+        acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa, fb, acc, 4, 4, 0, SCALE, 0, SCALE);
+    }
+    for (int r = 0; r < 4; ++r) out[(4 * (l >> 4) + r) * 16 + (l & 15)] = acc[r];
+}
+
+template <int NACC>
+__global__ void rate_kernel(int iters, float* out) {
+    v8i fa, fb;
+    for (int i = 0; i < 8; ++i) { fa[i] = 0x22222222 * (i < 4); fb[i] = 0x20202020 * (i < 4); }
+    v4f acc[NACC];
+    for (int i = 0; i < NACC; ++i) acc[i] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+        for (int i = 0; i < NACC; ++i)
+            acc[i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa, fb, acc[i], 4, 4, 0, 0, 0, 0);
+    float s = 0;
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][3];
+    if (s == 12345.f) out[0] = s;
+}
+
+int main() {
+    std::vector<uint32_t> a(128), b(128);
+    uint64_t st = 88172645463325252ull;
+    auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (uint32_t)(st >> 16); };
+    for (auto& v : a) v = rnd();
+    for (auto& v : b) v = rnd() & rnd();  // asymmetric densities
+    uint32_t *da, *db; float* dout;
+    hipMalloc(&da, 512); hipMalloc(&db, 512); hipMalloc(&dout, 1024);
+    hipMemcpy(da, a.data(), 512, hipMemcpyHostToDevice);
+    hipMemcpy(db, b.data(), 512, hipMemcpyHostToDevice);
+    for (int variant = 0; variant < 2; ++variant) {
+        hipMemset(dout, 0, 1024);
+        if (variant == 0) probe_kernel<0><<<1, 64>>>(da, db, dout);
+        else probe_kernel<0x7F7F7F7F><<<1, 64>>>(da, db, dout);
+        float out[256];
+        hipMemcpy(out, dout, 1024, hipMemcpyDeviceToHost);
+        int bad = 0;
+        for (int i = 0; i < 16; ++i)
+            for (int j = 0; j < 16; ++j) {
+                int ref = 0;
+                for (int w = 0; w < 8; ++w) ref += __builtin_popcount(a[i * 8 + w] & b[j * 8 + w]);
+                if (out[i * 16 + j] != (float)ref) {
+                    if (bad < 4) printf("  [%d][%d] got %g want %d\n", i, j, out[i * 16 + j], ref);
+                    ++bad;
+                }
+            }
+        printf("scale operand %s: %d / 256 wrong\n", variant == 0 ? "0" : "0x7F7F7F7F", bad);
+    }
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int iters = 20000;
+    for (int waves = 1; waves <= 4; waves *= 2) {
+        rate_kernel<8><<<256 * 8, 64 * 4 * waves>>>(16, dout);  // warm
+        hipEventRecord(e0);
+        rate_kernel<8><<<256 * 8, 64 * 4 * waves>>>(iters, dout);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        double mfma = 256.0 * 8 * 4 * waves * iters * 8;
+        printf("%d wave(s)/SIMD x 8 blocks/CU: %.3f ms, %.2f T pairs/s (2 MFMA per 256 pairs), %.2f PFLOP/s\n", waves, ms,
+               mfma * 128 / (ms * 1e-3) / 1e12, mfma * 65536 / (ms * 1e-3) / 1e15);
+    }
+    return 0;
+}
