@@ -1,7 +1,7 @@
 // The matrix-core 256-bit matcher.  Its own translation unit because it is built with
 // -fno-honor-nans (no v_max_f32 x, x, x canonicalisation in front of every maximum; every value
 // here is a finite integer) and -mllvm -amdgpu-mfma-vgpr-form (MFMA results land in VGPRs, where
-// v_max_f32 can read them, instead of AGPRs + v_accvgpr_read).  Nothing in this file depends on
+// v_max3_f32 can read them, instead of AGPRs + v_accvgpr_read).  Nothing in this file depends on
 // include/orbfe_math.h's rounding contract.
 #include "device_common.hpp"
 #include "orbfe_internal.hpp"
@@ -21,17 +21,27 @@ namespace orbfe {
 //     of the 256 bits inside K does not matter as long as both frames use the same one).  It
 //     also writes colkey[j] = -(|b_j| * S + j), S = 16384 (-1e30 for padding).
 // (2) match_mfma_kernel: block = 128 queries of frame p (8 A fragments x 2 k-steps, resident
-//     in VGPRs), its 4 waves take every 4th block of 16 candidates of frame p + 1.  B is
-//     block-scaled by 2^15 = 2S (E8M0 142) and the accumulator starts at colkey[j], so the
-//     MFMA pair itself yields key' = 2S a.b - S|b_j| - j = -(S (dist - |a|) + j) exactly, and
-//     the whole epilogue is one v_max_f32 per pair: the maximum key' is the lexicographic
+//     in VGPRs), its 4 waves take every 4th block of 16 candidates of frame p + 1, streamed
+//     through a per-wave LDS ring by LDS-DMA.  B is block-scaled by 2^15 = 2S (E8M0 142) and
+//     the accumulator starts at colkey[j], so the MFMA pair itself yields
+//     key' = 2S a.b - S|b_j| - j = -(S (dist - |a|) + j) exactly, and the whole epilogue is a
+//     running maximum (one v_max3_f32 per two pairs): the maximum key' is the lexicographic
 //     minimum (dist, j), the same winner as the packed-key v_min_u32 of the VALU kernel.
 //     The 64 partial maxima per query (4 waves x 16 column classes) are reduced through LDS.
+// Measured (tools/mfma_probe.hip, MI355X): the MFMA alone issues at 19 T pairs/s; with the
+// epilogue as v_max_f32 the step structure tops out at 12.5 T (VALU issue does not overlap these
+// MFMAs), with v_max3_f32 at 14.7 T; the kernel reaches ~11 T.
 constexpr int kMmaS = 16384;
 constexpr int kMmaRows = 128;
 constexpr int kMmaLds = 68; // floats per query row in LDS: 64 + 4 keeps writes and b128 reads conflict-free
+constexpr int kRing = 4;                 // candidate blocks in flight per wave
+constexpr int kSlotBytes = 2048 + 256;   // one block: 2 x 1 KB fragments + 16 column keys x 4 copies (a b128 read = the C tuple)
+constexpr int kRingBytes = 4 * kRing * kSlotBytes;
+constexpr int kBestBytes = kMmaRows * kMmaLds * 4;
+constexpr int kMmaLdsBytes = kRingBytes > kBestBytes ? kRingBytes : kBestBytes;
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // 8 bits -> 8 e2m1 nibbles (bit b -> nibble b): 0x2 (= 1.0) or 0
 __device__ __forceinline__ uint32_t spread_bits_e2m1(uint32_t x)
@@ -63,15 +73,18 @@ match_expand_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *_
     if (w == 0) mkey[(size_t)f * capP + i] = live ? -(float)(pop * kMmaS + i) : -1e30f;
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
 match_mfma_kernel(const uint4 *__restrict__ mexp, const float *__restrict__ mkey, const int32_t *__restrict__ counts,
                   int cap, int capP, int max_dist, int32_t *__restrict__ out_idx, int32_t *__restrict__ out_dist)
 {
-    __shared__ float s_best[kMmaRows * kMmaLds];
+    // the candidate ring while the MFMA loop runs, then (after a barrier) the partial maxima
+    __shared__ __attribute__((aligned(16))) unsigned char s_mem[kMmaLdsBytes];
+    float *s_best = reinterpret_cast<float *>(s_mem);
     int p, blk;
     xcd_remap(gridDim.x, gridDim.y, &p, &blk); // all query blocks of a pair share one L2
     const int nA = counts[p], nB = counts[p + 1];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform: block indices stay in SGPRs
     const int row0 = blk * kMmaRows;
     const uint4 *__restrict__ Ea = mexp + (size_t)p * capP * 8;
     const uint4 *__restrict__ Eb = mexp + (size_t)(p + 1) * capP * 8;
@@ -94,39 +107,82 @@ match_mfma_kernel(const uint4 *__restrict__ mexp, const float *__restrict__ mkey
 #pragma unroll
         for (int m = 0; m < 8; m++) best[m] = (v4f){-3e38f, -3e38f, -3e38f, -3e38f};
         const int nBb = (nB + 15) >> 4;
-        int bb = wv;
-        uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
-        float c = -1e30f;
-        if (bb < nBb) {
-            q0 = Eb[(size_t)bb * 128 + lane];
-            q1 = Eb[(size_t)bb * 128 + 64 + lane];
-            c = Kb[bb * 16 + (lane & 15)];
-        }
-        while (bb < nBb) {
-            const int nb = bb + 4;
-            uint4 n0 = q0, n1 = q1;
-            float nc = c;
-            if (nb < nBb) { // prefetch the next candidate block under this one's MFMAs
-                n0 = Eb[(size_t)nb * 128 + lane];
-                n1 = Eb[(size_t)nb * 128 + 64 + lane];
-                nc = Kb[nb * 16 + (lane & 15)];
-            }
+        // This wave's candidate blocks wv, wv + 4, ... stream through a ring of kRing LDS slots
+        // filled by LDS-DMA (global_load_lds: no VGPRs, nothing the register allocator could
+        // copy while in flight).  The fragment layout written by match_expand_kernel is exactly
+        // lane-linear, so one 16-byte DMA per k-step lands as the operand image.  Each slot is
+        // filled by exactly 3 DMAs and VMEM retires in order, so slot s is complete once at
+        // most 3 * (kRing - 1) younger DMAs are outstanding.  Past the wave's last block the
+        // index is clamped: every step issues its 3 DMAs and the count stays exact.
+        unsigned char *ring = s_mem + wv * (kRing * kSlotBytes);
+        const uint32_t ring_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)ring;
+        const uint32_t lds16 = ring_lds + lane * 16, ldsk = ring_lds + (lane & 15) * 16; // this lane's read addresses
+        const int T = wv < nBb ? (nBb - wv + 3) >> 2 : 0; // blocks of this wave
+        auto issue = [&](int s, int t) {
+            int lb = wv + 4 * t;
+            lb = lb < nBb ? lb : nBb - 1;
+            const uint4 *src = Eb + (size_t)lb * 128 + lane;
+            unsigned char *dst = ring + s * kSlotBytes; // wave-uniform; lane L lands at dst + size * L
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 64),
+                                             (__attribute__((address_space(3))) void *)(dst + 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Kb + lb * 16 + (lane >> 2)),
+                                             (__attribute__((address_space(3))) void *)(dst + 2048), 4, 0, 0);
+        };
+        // One step = TWO candidate blocks (slots s, s + 1; s even).  On this chip VALU issue does
+        // not overlap these MFMAs (a step of 16 MFMAs + 32 v_max_f32 measures 381 cycles, not
+        // 256), so the epilogue is cut to ONE v_max3_f32 per two results: max3(best, blockA,
+        // blockB).  The column keys sit in LDS as 16 keys x 4 copies, so one ds_read_b128 IS the
+        // 4-register accumulator-init tuple (no v_mov broadcast).
+        // The slots are read with hand-written ds_reads: hipcc would put its own vmcnt(0) in front
+        // of a compiler-visible LDS read that may alias a pending DMA.  Reads and their wait are
+        // ONE asm block: no register is in flight outside it.
+        auto step2 = [&](int s, int t) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (kRing - 2)) : "memory");
+            u32x4 q0, q1, p0, p1;
+            v4f cv, dv;
+            asm volatile("ds_read_b128 %0, %6 offset:%8\n\tds_read_b128 %1, %6 offset:%9\n\t"
+                         "ds_read_b128 %2, %7 offset:%10\n\t"
+                         "ds_read_b128 %3, %6 offset:%11\n\tds_read_b128 %4, %6 offset:%12\n\t"
+                         "ds_read_b128 %5, %7 offset:%13\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(q0), "=&v"(q1), "=&v"(cv), "=&v"(p0), "=&v"(p1), "=&v"(dv)
+                         : "v"(lds16), "v"(ldsk), "n"(s * kSlotBytes), "n"(s * kSlotBytes + 1024),
+                           "n"(s * kSlotBytes + 2048), "n"((s + 1) * kSlotBytes), "n"((s + 1) * kSlotBytes + 1024),
+                           "n"((s + 1) * kSlotBytes + 2048)
+                         : "memory");
             const v8i b0 = (v8i){(int)q0.x, (int)q0.y, (int)q0.z, (int)q0.w, 0, 0, 0, 0};
             const v8i b1 = (v8i){(int)q1.x, (int)q1.y, (int)q1.z, (int)q1.w, 0, 0, 0, 0};
-            const v4f cv = (v4f){c, c, c, c};
+            const v8i d0 = (v8i){(int)p0.x, (int)p0.y, (int)p0.z, (int)p0.w, 0, 0, 0, 0};
+            const v8i d1 = (v8i){(int)p1.x, (int)p1.y, (int)p1.z, (int)p1.w, 0, 0, 0, 0};
 #pragma unroll
             for (int m = 0; m < 8; m++) {
                 // cbsz = blgp = 4: e2m1 operands; scales are E8M0 bytes: A x 2^0 (127), B x 2^15 (142)
                 v4f acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m][0], b0, cv, 4, 4, 0, 127, 0, 142);
+                v4f acd = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m][0], d0, dv, 4, 4, 0, 127, 0, 142);
                 acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m][1], b1, acc, 4, 4, 0, 127, 0, 142);
+                acd = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m][1], d1, acd, 4, 4, 0, 127, 0, 142);
 #pragma unroll
-                for (int r = 0; r < 4; r++) best[m][r] = __builtin_fmaxf(best[m][r], acc[r]);
+                for (int r = 0; r < 4; r++)
+                    best[m][r] = __builtin_fmaxf(__builtin_fmaxf(best[m][r], acc[r]), acd[r]); // v_max3_f32
             }
-            q0 = n0;
-            q1 = n1;
-            c = nc;
-            bb = nb;
+            // the slots are refilled only after their reads: the MFMAs above consumed them
+            issue(s, t + kRing);
+            issue(s + 1, t + 1 + kRing);
+        };
+        static_assert(kRing == 4, "the loop below is written for 4 slots = 2 double steps");
+#pragma unroll
+        for (int s = 0; s < kRing; s++) issue(s, s);
+        // a block past the wave's last one is the clamped last block again: maxima are idempotent
+        int t = 0;
+        for (; t + 4 <= T; t += 4) {
+            step2(0, t);
+            step2(2, t + 2);
         }
+        if (t < T) step2(0, t);
+        if (t + 2 < T) step2(2, t + 2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // drain the clamped tail DMAs
+        __syncthreads();                                  // every wave is done with its ring: s_best reuses it
         // C/D layout: lane holds rows 4 * (lane >> 4) + r of each 16-row fragment, column lane & 15
 #pragma unroll
         for (int m = 0; m < 8; m++)

@@ -37,7 +37,7 @@ __global__ void probe_kernel(const uint32_t* a_bits, const uint32_t* b_bits, flo
     for (int r = 0; r < 4; ++r) out[(4 * (l >> 4) + r) * 16 + (l & 15)] = acc[r];
 }
 
-template <int NACC>
+template <int NACC, int SA = 0, int SB = 0>
 __global__ void rate_kernel(int iters, float* out) {
     v8i fa, fb;
     for (int i = 0; i < 8; ++i) { fa[i] = 0x22222222 * (i < 4); fb[i] = 0x20202020 * (i < 4); }
@@ -46,10 +46,65 @@ __global__ void rate_kernel(int iters, float* out) {
     for (int it = 0; it < iters; ++it)
 #pragma unroll
         for (int i = 0; i < NACC; ++i)
-            acc[i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa, fb, acc[i], 4, 4, 0, 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa, fb, acc[i], 4, 4, 0, SA, 0, SB);
     float s = 0;
     for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][3];
     if (s == 12345.f) out[0] = s;
+}
+
+// two candidate blocks per step, one v_max3_f32 per pair of results
+__global__ void __launch_bounds__(256) step3_kernel(int iters, const int* seed, float* out) {
+    v8i a[8][2], b0, b1, d0, d1;
+    for (int m = 0; m < 8; ++m)
+        for (int k = 0; k < 2; ++k)
+            for (int i = 0; i < 8; ++i) a[m][k][i] = (i < 4) ? (seed[(m * 2 + k) & 3] + threadIdx.x * (m + 3 * k + i)) & 0x22222222 : 0;
+    for (int i = 0; i < 8; ++i) { b0[i] = (i < 4) ? seed[1] & 0x22222222 : 0; b1[i] = (i < 4) ? seed[2] & 0x22222222 : 0;
+                                  d0[i] = (i < 4) ? seed[0] & 0x22222222 : 0; d1[i] = (i < 4) ? seed[1] & 0x02222222 : 0; }
+    v4f best[8];
+    for (int m = 0; m < 8; ++m) best[m] = (v4f){-3e38f, -3e38f, -3e38f, -3e38f};
+    float c = (float)seed[3];
+    for (int it = 0; it < iters; ++it) {
+        v4f cv = {c, c, c, c}, dv = {c + 0.5f, c + 0.5f, c + 0.5f, c + 0.5f};
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            v4f acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m][0], b0, cv, 4, 4, 0, 127, 0, 142);
+            acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m][1], b1, acc, 4, 4, 0, 127, 0, 142);
+            v4f acd = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m][0], d0, dv, 4, 4, 0, 127, 0, 142);
+            acd = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m][1], d1, acd, 4, 4, 0, 127, 0, 142);
+            for (int r = 0; r < 4; ++r) best[m][r] = __builtin_fmaxf(__builtin_fmaxf(best[m][r], acc[r]), acd[r]);
+        }
+        c += 1.0f;
+        b0[0] ^= 0x2; b1[1] ^= 0x20; d0[2] ^= 0x200; d1[3] ^= 0x2000;
+    }
+    float s = 0;
+    for (int m = 0; m < 8; ++m) s += best[m][0] + best[m][1] + best[m][2] + best[m][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+// the matcher's step: 8 resident A fragments x 2 k-steps, acc preloaded, 32 maxima; no memory
+__global__ void __launch_bounds__(256) step_kernel(int iters, const int* seed, float* out) {
+    v8i a[8][2], b0, b1;
+    for (int m = 0; m < 8; ++m)
+        for (int k = 0; k < 2; ++k)
+            for (int i = 0; i < 8; ++i) a[m][k][i] = (i < 4) ? (seed[(m * 2 + k) & 3] + threadIdx.x * (m + 3 * k + i)) & 0x22222222 : 0;
+    for (int i = 0; i < 8; ++i) { b0[i] = (i < 4) ? seed[1] & 0x22222222 : 0; b1[i] = (i < 4) ? seed[2] & 0x22222222 : 0; }
+    v4f best[8];
+    for (int m = 0; m < 8; ++m) best[m] = (v4f){-3e38f, -3e38f, -3e38f, -3e38f};
+    float c = (float)seed[3];
+    for (int it = 0; it < iters; ++it) {
+        v4f cv = {c, c, c, c};
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            v4f acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m][0], b0, cv, 4, 4, 0, 127, 0, 142);
+            acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m][1], b1, acc, 4, 4, 0, 127, 0, 142);
+            for (int r = 0; r < 4; ++r) best[m][r] = __builtin_fmaxf(best[m][r], acc[r]);
+        }
+        c += 1.0f;
+        b0[0] ^= 0x2; b1[1] ^= 0x20;
+    }
+    float s = 0;
+    for (int m = 0; m < 8; ++m) s += best[m][0] + best[m][1] + best[m][2] + best[m][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
 int main() {
@@ -91,6 +146,40 @@ int main() {
         double mfma = 256.0 * 8 * 4 * waves * iters * 8;
         printf("%d wave(s)/SIMD x 8 blocks/CU: %.3f ms, %.2f T pairs/s (2 MFMA per 256 pairs), %.2f PFLOP/s\n", waves, ms,
                mfma * 128 / (ms * 1e-3) / 1e12, mfma * 65536 / (ms * 1e-3) / 1e15);
+    }
+    for (int waves = 1; waves <= 4; waves *= 2) {
+        rate_kernel<8, 127, 142><<<256 * 8, 64 * 4 * waves>>>(16, dout);
+        hipEventRecord(e0);
+        rate_kernel<8, 127, 142><<<256 * 8, 64 * 4 * waves>>>(iters, dout);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        double mfma = 256.0 * 8 * 4 * waves * iters * 8;
+        printf("SCALED %d wave(s)/SIMD: %.3f ms, %.2f T pairs/s, %.2f PFLOP/s\n", waves, ms,
+               mfma * 128 / (ms * 1e-3) / 1e12, mfma * 65536 / (ms * 1e-3) / 1e15);
+    }
+    {
+        int hseed[4] = {0x22222222, 0x22022202, 0x20222220, 7};
+        int* dseed; float* dbig;
+        hipMalloc(&dseed, 16); hipMalloc(&dbig, 256 * 4 * 256 * 4 * 4);
+        hipMemcpy(dseed, hseed, 16, hipMemcpyHostToDevice);
+        for (int bpc = 1; bpc <= 4; ++bpc) {  // blocks of 4 waves per CU = waves per SIMD
+            step_kernel<<<256 * bpc, 256>>>(16, dseed, dbig);
+            hipEventRecord(e0);
+            step_kernel<<<256 * bpc, 256>>>(2000, dseed, dbig);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            double mfma = 256.0 * bpc * 4 * 2000 * 16;
+            printf("STEP structure, %d wave(s)/SIMD: %.3f ms, %.2f T pairs/s\n", bpc, ms, mfma * 128 / (ms * 1e-3) / 1e12);
+        }
+        for (int bpc = 1; bpc <= 3; ++bpc) {
+            step3_kernel<<<256 * bpc, 256>>>(16, dseed, dbig);
+            hipEventRecord(e0);
+            step3_kernel<<<256 * bpc, 256>>>(1000, dseed, dbig);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            double mfma = 256.0 * bpc * 4 * 1000 * 32;
+            printf("STEP3 (max3 over 2 blocks), %d wave(s)/SIMD: %.3f ms, %.2f T pairs/s\n", bpc, ms, mfma * 128 / (ms * 1e-3) / 1e12);
+        }
     }
     return 0;
 }
