@@ -38,6 +38,7 @@ MODES = {
                 workload="640x480 mono, reference-parity mode (6 levels, cell 32, FAST-12 t=13, "
                          "<=300 keypoints), 32-bit windowed match t-1->t"),
 }
+FP4_MFMA_PEAK_TFLOPS = 10000.0
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -249,7 +250,7 @@ def main():
             float((12 * (c64[:-1] + c64[1:]) + 8 * c64[:-1]).sum()) / B
         kernels = {"pyramid": "pyramid_fused_kernel", "detect": "detect_tile_kernel",
                    "describe": "select_kernel+describe_kernel",
-                   "match": "match_gather_kernel+match_batch_256_kernel" if mm["mode"] == 1 else "match_batch_ref_kernel"}
+                   "match": "match_expand_kernel+match_mfma_kernel" if mm["mode"] == 1 else "match_batch_ref_kernel"}
         traffic_all = {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and B == 256:  # the PMC passes were taken at batch 256
@@ -261,6 +262,14 @@ def main():
                          "achieved_GBps": ab[k] * B / (stages[k] * 1e-3) / 1e9,
                          "frac": ab[k] * B / (stages[k] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                          "traffic": traffic_all.get(k)} for k in stages}
+        if mm["mode"] == 1:
+            # the 256-bit matcher runs on the matrix cores: 2 x 256 flop per pair on e2m1 operands,
+            # dense FP4 MFMA peak ~10 PFLOP/s (MI355X_MICROARCH.md, Matrix cores)
+            flops = 512.0 * pairs_local
+            per_stage["match"]["mfma"] = {"bound": "mfma", "unit": "TFLOP/s", "peak": FP4_MFMA_PEAK_TFLOPS,
+                                          "achieved": flops / (ms_match * 1e-3) / 1e12,
+                                          "frac": flops / (ms_match * 1e-3) / 1e12 / FP4_MFMA_PEAK_TFLOPS,
+                                          "flops_per_launch": flops}
         dom = max(stages, key=lambda k: stages[k])  # the kernel with the largest share of the step
         dom_kernel = kernels[dom]
         achieved = per_stage[dom]["achieved_GBps"]

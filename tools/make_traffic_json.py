@@ -29,7 +29,8 @@ stages = {
     "pyramid": b("pyramid_fused_kernel") + b("blur_batch_kernel") + b("halfsample_batch_kernel"),
     "detect": b("detect_tile_kernel"),
     "describe": b("select_kernel") + b("describe_kernel"),
-    "match": b("match_gather_kernel") + b("match_batch_256_kernel") + b("match_batch_ref_kernel"),
+    "match": b("match_gather_kernel") + b("match_batch_256_kernel") + b("match_batch_ref_kernel")
+             + b("match_expand_kernel") + b("match_mfma_kernel"),
 }
 try:
     allj = json.load(open(out))
