@@ -513,6 +513,46 @@ def test_match_batch_256_crafted_records(gpu, oracle_mod, w, h, kw, maxd):
     assert torch.equal(d_idx, d_idx2)
 
 
+@pytest.mark.parametrize("maxf,path", [(16384, "matrix cores, index uses all 14 bits"),
+                                       (16400, "VALU kernel: more than 16384 keypoints per frame")])
+def test_match_batch_256_at_the_key_packing_limit(gpu, oracle_mod, maxf, path):
+    """The matrix-core matcher packs (distance, index) into one f32-exact integer with a 14-bit
+    index: 16384 keypoints per frame is its limit and the last index must still win / tie-break
+    correctly; one keypoint more takes the VALU kernel.  Same results either way."""
+    torch, orbfe = gpu
+    ctx = orbfe.Context(2048, 1024, max_batch=2, cell=8, max_features=maxf)  # K = 32768 cells
+    cap = ctx.cap
+    assert cap == maxf
+    rng = np.random.default_rng(maxf)
+    rec = np.zeros((2, cap), orbfe.KEYPOINT_DTYPE)
+    rec["desc"] = rng.integers(0, 256, (2, cap, 32), dtype=np.uint8)
+    # query 0's only exact partner is the LAST candidate; queries 1 and 2 have two exact partners
+    # (cap - 3 and cap - 2): the lower index wins
+    rec["desc"][1, cap - 1] = rec["desc"][0, 0]
+    rec["desc"][1, cap - 2] = rec["desc"][0, 1]
+    rec["desc"][1, cap - 3] = rec["desc"][0, 1]
+    rec["desc"][0, 2] = rec["desc"][0, 1]
+    # extreme popcounts: distance 256 and 0 against all-ones / all-zeros
+    rec["desc"][0, 3] = 0
+    rec["desc"][0, 4] = 255
+    rec["desc"][1, 7] = 255
+    rec["desc"][1, 9] = 0
+    counts = np.array([cap, cap], np.int32)
+    d_rec = dev(torch, rec.view(np.uint8).reshape(-1))
+    d_cnt = dev(torch, counts)
+    d_idx = torch.full((cap,), -7, dtype=torch.int32, device="cuda")
+    d_dist = torch.full((cap,), -7, dtype=torch.int32, device="cuda")
+    ctx.match_batch(d_rec.data_ptr(), d_cnt.data_ptr(), 2, 1, -1, 256, d_idx.data_ptr(), d_dist.data_ptr(),
+                    stream(torch))
+    idx, dist = d_idx.cpu().numpy(), d_dist.cpu().numpy()
+    ref_idx, ref_dist = oracle_mod.match256(rec["desc"][0], rec["desc"][1], None, None, -1, 256)
+    np.testing.assert_array_equal(idx, ref_idx)
+    np.testing.assert_array_equal(dist, ref_dist)
+    assert idx[0] == cap - 1 and dist[0] == 0
+    assert idx[1] == cap - 3 and idx[2] == cap - 3 and dist[1] == 0
+    assert dist[3] == 0 and idx[3] == 9 and dist[4] == 0 and idx[4] == 7
+
+
 # ------------------------------------------------------------------ full-size properties
 def test_full_size_batch_properties(gpu, oracle_mod):
     """BASELINE configs[1] at bench size (batch 256): size-independent properties.
