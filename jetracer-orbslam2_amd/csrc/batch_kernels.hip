@@ -595,24 +595,88 @@ select_kernel(DeviceGeom g, const uint32_t *__restrict__ cellkey, uint4 *__restr
 // ------------------------------------------------------------------------------------
 // The patch a keypoint needs (radius R: 15 for the moments disc and the reference-mode
 // descriptor, 19 once the descriptor really rotates) is staged in LDS by the wave with
-// independent, row-contiguous dword loads (one memory latency instead of ~20 dependent byte
-// gathers); moments and the 512 descriptor samples then read LDS bytes.
+// independent LDS-DMA loads (one memory latency instead of ~20 dependent byte gathers); moments
+// and the 512 descriptor samples then read LDS.
+// Staging is the largest part of this kernel and is bound by the texture path, which wants every
+// quad of lanes to fetch 16 contiguous bytes: with 4-byte DMAs over 36-byte rows (9 dwords, quads
+// straddling rows) the stage took 0.226 ms, with 32-byte rows 0.174 ms, unaligned origins were
+// slower still (ablations in DESIGN.md 4.3).  So the patch origin is ((x - R) & ~15, y - R), rows are
+// 48 (R = 15) / 64 (R = 19) bytes, and one lane moves one aligned 16-byte chunk
+// (global_load_lds_dwordx4): 2 / 3 DMA instructions per patch.  The keypoint sits at byte
+// (R, R + phase) of its patch, phase = (x - R) & 15.
 constexpr int kKpw = 4; // keypoints per wave (consecutive slots = neighbouring cells)
+
+template <int R>
+struct PatchGeom {
+    static constexpr int kRows = 2 * R + 1;
+    // bytes one lane stages.  (The 12-byte LDS-DMA would fit 36-byte rows, but it writes lane L at
+    // LDS base + 16 L, leaving a 4-byte hole after every 12 bytes: tools/dma12_probe.hip.)
+    static constexpr int kChunk = 16;
+    static constexpr int kAlign = 16;                              // alignment of the patch origin
+    static constexpr int kPitch = (2 * R + 1 + kAlign - 1 + kChunk - 1) / kChunk * kChunk; // 48 / 64
+    static constexpr int kChunksRow = kPitch / kChunk;
+    static constexpr int kChunks = kRows * kChunksRow;             // chunks per patch
+    static constexpr int kTrips = (kChunks + 63) / 64;             // DMA instructions per patch
+    static constexpr int kPatchBytes = (kChunks * kChunk + 3) / 4 * 4;
+    // Intensity-centroid moments on the matrix cores: m10 = sum dx * I, m01 = sum dy * I over
+    // the radius-15 disc are dot products of the patch bytes with fixed weights.  One
+    // v_mfma_i32_16x16x64_i8 takes 16 rows x 64 bytes: row = (keypoint, K slice s), 4 keypoints x
+    // 4 slices of 64 consecutive patch bytes; column = (slice s', x or y weights) -- the entries
+    // with s = s' are the partial sums, the rest is ignored.  kMom such steps cover the 31 disc
+    // rows (which start kStart bytes into the patch).  The alignment phase is absorbed by reading
+    // the A fragment at byte address patch + phase (a misaligned ds_read_b128, which gfx950
+    // serves): the linear byte stream shifted by phase has the keypoint at column R of every
+    // row, and the bytes that wrap into the next row fall on columns >= kPitch - 15 > 30, whose
+    // weight is 0.  Pixels enter as I ^ 0x80 (signed I - 128); exact, because the disc's weights
+    // sum to zero.
+    static constexpr int kStart = (R - 15) * kPitch;          // multiple of 16
+    static constexpr int kMom = (31 * kPitch + 255) / 256;    // 6 (R = 15) / 8 (R = 19)
+    static_assert(kPitch - (kAlign - 1) > 30, "wrapped bytes must fall outside the disc columns");
+};
+
+// Weight operand of the moment MFMAs for patch radius R, in B-fragment order [kMom][lane 64][16]:
+// lane = 16 * chunk + column, column = 2 * slice + (0: dx weights, 1: dy weights), columns 8..15 zero.
+// Disc chords: orb.cu:79-80 (u_max), the same table as c_umax in device_common.hpp.
+static std::vector<int8_t> make_moment_weights(int R)
+{
+    static const int u[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 7, 5, 0};
+    const int pitch = R == 15 ? PatchGeom<15>::kPitch : PatchGeom<19>::kPitch, start = (R - 15) * pitch,
+              n = (31 * pitch + 255) / 256;
+    std::vector<int8_t> w((size_t)n * 64 * 16, 0);
+    for (int ks = 0; ks < n; ks++)
+        for (int lane = 0; lane < 64; lane++) {
+            const int col = lane & 15, c = lane >> 4;
+            if (col >= 8) continue;
+            const int sl = col >> 1, xy = col & 1;
+            for (int j = 0; j < 16; j++) {
+                const int pb = start + ks * 256 + sl * 64 + c * 16 + j; // patch byte
+                const int dy = pb / pitch - R, dx = pb % pitch - R;
+                const int ady = dy < 0 ? -dy : dy, adx = dx < 0 ? -dx : dx;
+                if (ady <= 15 && adx <= u[ady]) w[((size_t)ks * 64 + lane) * 16 + j] = (int8_t)(xy ? dy : dx);
+            }
+        }
+    return w;
+}
 
 // One wave = kKpw keypoints, in three passes so that the transcendental math is not repeated
 // by all 64 lanes for every keypoint:
-//   1  stage the kKpw patches in LDS and reduce their moments (wave-uniform integers)
+//   1  stage the kKpw patches in LDS; their moments = kMom int8 MFMAs for all four at once
 //   2  lanes 0..kKpw-1 each take one keypoint: atan2f, steering cos/sin -- ONCE per wave
 //   3  per keypoint: 256 rotated tests from its LDS patch, 4 ballots = the descriptor
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 template <int R>
 __global__ void __launch_bounds__(256)
 describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__restrict__ sel,
-                const int32_t *__restrict__ selcount, orbfe_keypoint *__restrict__ records, orbfe_soa soa)
+                const int32_t *__restrict__ selcount, const uint4 *__restrict__ momw,
+                orbfe_keypoint *__restrict__ records, orbfe_soa soa)
 {
-    constexpr int kRows = 2 * R + 1;
-    constexpr int kDw = (2 * R + 3) / 4 + 1; // dwords per patch row incl. alignment slack
-    constexpr int kPatch = kRows * kDw;
-    __shared__ uint32_t s_patch[4][kKpw][kPatch];
+    using G = PatchGeom<R>;
+    constexpr int kRows = G::kRows, kPitch = G::kPitch, kPatchBytes = G::kPatchBytes;
+    // + 256 bytes: the last moment step of the last patch reads (zero-weighted) bytes past it
+    __shared__ __attribute__((aligned(16))) uint8_t s_patch[4 * kKpw * kPatchBytes + 256];
+    static_assert(G::kStart + G::kMom * 256 + 15 <= kPatchBytes + 256, "moment reads stay inside s_patch");
 
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // scalar: wave-uniform
@@ -625,9 +689,22 @@ describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__re
     const uint8_t *img = pyr + (size_t)f * g.frame_stride + g.lv[0].offset;
     const int P = g.lv[0].pitch;
     const uint4 *fsel = sel + (size_t)f * g.cap + slot0;
+    uint8_t *wpatch = s_patch + wv * (kKpw * kPatchBytes); // this wave's kKpw patches
+    // weight fragments of the moment MFMAs: issued first, they arrive under the patch staging
+    uint4 bw[G::kMom];
+#pragma unroll
+    for (int ks = 0; ks < G::kMom; ks++) bw[ks] = momw[ks * 64 + lane];
 
     int kx[kKpw], ky[kKpw], kax[kKpw], m10[kKpw], m01[kKpw];
     uint32_t kcell[kKpw], kkey[kKpw];
+    // chunk c of a patch = (row c / kChunksRow, 16-byte column c % kChunksRow); trip t stages chunks
+    // 64 t + lane.  Their image offsets relative to the patch origin, once per wave.
+    uint32_t voff[G::kTrips];
+#pragma unroll
+    for (int t = 0; t < G::kTrips; t++) {
+        const int c = 64 * t + lane, r = c / G::kChunksRow;
+        voff[t] = (uint32_t)(__mul24(r, P) + G::kChunk * (c - r * G::kChunksRow));
+    }
     // ---- pass 1: stage + moments
 #pragma unroll
     for (int it = 0; it < kKpw; it++) {
@@ -641,54 +718,43 @@ describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__re
         kx[it] = x;
         ky[it] = y;
         const int oy = y - R;
-        const int ax = (x - R) & ~3; // x >= 3, R <= 19: may be negative, still a multiple of 4
+        const int ax = (x - R) & ~(G::kAlign - 1); // may be negative, still a multiple of kAlign
         kax[it] = ax;
-        uint32_t *sp = s_patch[wv][it];
-        // dword i of the patch = (row i / kDw, column dword i % kDw); i advances by 64 per trip,
-        // so (row, dword) advance by (64 / kDw, 64 % kDw) with one carry: no divisions
-        int r = lane / kDw, q = lane - r * kDw;
-        // interior keypoints (the patch touches no excluded row / column): plain copies
-        const bool inner = oy > 0 && oy + kRows <= g.H && ax > 0 && ax + 4 * kDw <= g.W; // uniform
+        uint8_t *sp = wpatch + it * kPatchBytes;
+        // Plain copies when (a) every chunk lies inside the image's rows and padded pitch and (b) the
+        // disc meets no excluded pixel (row <= 0, row >= H, column <= 0, column >= W: orb.cu:98,112,
+        // 119).  Bytes outside the disc or the image width then carry zero weight and are never
+        // sampled by the descriptor (17 / 19-px guard band), so their values do not matter.
+        const bool inner = oy >= 0 && oy + kRows <= g.H && ax >= 0 && ax + kPitch <= P && y > 15 && y + 15 < g.H &&
+                           x > 15 && x + 15 < g.W; // uniform
         if (inner) {
-            // LDS-DMA: global_load_lds_dword writes lane L's dword to (uniform LDS base) + 4 L with
-            // no VGPR round trip and no ds_write; the base advances by 64 dwords per trip
-            uint32_t off = (uint32_t)(__mul24(oy + r, P) + ax + 4 * q);
-            const uint32_t dstep = (uint32_t)((64 / kDw) * P + 4 * (64 % kDw)); // offset step per trip
+            // LDS-DMA: global_load_lds_dwordx4 writes lane L's 16 bytes to (uniform LDS base) + 16 L
+            // with no VGPR round trip and no ds_write.  Address = scalar patch origin + the lane's
+            // patch-relative offset of this trip: no VALU per DMA; every lane address is 16-byte
+            // aligned (P is a multiple of 64).
+            const uint8_t *pb = img + ((ptrdiff_t)oy * P + ax);
 #pragma unroll
-            for (int i0 = 0; i0 < kPatch; i0 += 64) {
-                const int i = i0 + lane;
-                if (i0 + 64 <= kPatch || i < kPatch)
-                    __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void *)(img + off),
-                        (__attribute__((address_space(3))) void *)(sp + i0), 4, 0, 0);
-                off += dstep;
-                q += 64 % kDw;
-                if (q >= kDw) { // carry into the next row
-                    q -= kDw;
-                    off += (uint32_t)(P - 4 * kDw);
-                }
+            for (int t = 0; t < G::kTrips; t++) {
+                // (the size must be a literal: a template-dependent constant there keeps the host pass
+                // from emitting the kernel's stub)
+                static_assert(G::kChunk == 16, "DMA size literal below");
+                if (64 * (t + 1) <= G::kChunks || 64 * t + lane < G::kChunks)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pb + voff[t]),
+                                                     (__attribute__((address_space(3))) void *)(sp + 1024 * t), 16, 0, 0);
             }
         } else {
-#pragma unroll
-            for (int i0 = 0; i0 < kPatch; i0 += 64) {
-                const int i = i0 + lane;
+            // border keypoints: dword by dword, excluded pixels staged as 0
+            for (int i = lane; i < kPatchBytes / 4; i += 64) {
+                const int r = i / (kPitch / 4), q = i - r * (kPitch / 4);
                 const int gy = oy + r, gx = ax + 4 * q;
                 uint32_t v = 0;
-                // pixels the moments exclude (row <= 0, row >= H, column <= 0, column >= W) are
-                // staged as 0; the descriptor never samples them (17-px guard band)
-                if (i < kPatch && gy > 0 && gy < g.H && gx >= 0 && gx < g.W) {
+                if (gy > 0 && gy < g.H && gx >= 0 && gx < g.W) {
                     v = *reinterpret_cast<const uint32_t *>(img + (uint32_t)(__mul24(gy, P) + gx));
                     if (gx == 0) v &= 0xFFFFFF00u;
                     const int nv = g.W - gx; // valid bytes in this dword
                     if (nv < 4) v &= (1u << (8 * nv)) - 1u;
                 }
-                if (i < kPatch) sp[i] = v;
-                r += 64 / kDw;
-                q += 64 % kDw;
-                if (q >= kDw) {
-                    q -= kDw;
-                    r += 1;
-                }
+                reinterpret_cast<uint32_t *>(sp)[i] = v;
             }
         }
     }
@@ -697,11 +763,39 @@ describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__re
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // LDS ops of one wave are in order
     __builtin_amdgcn_wave_barrier();
+    {
+        // A fragment: lane = 16 * chunk + row, row = keypoint + 4 * slice: 16 consecutive bytes of the
+        // phase-shifted patch stream.  Hand-written misaligned ds_read_b128 (a C++ uint4 load would
+        // promise 16-byte alignment); reads and their wait are one asm block.
+        const int row = lane & 15;
+        int phase = kx[0] - R - kax[0];
 #pragma unroll
-    for (int it = 0; it < kKpw; it++) {
-        if (it >= nk) continue;
-        const uint8_t *spb = reinterpret_cast<const uint8_t *>(s_patch[wv][it]);
-        patch_moments_staged(spb + R * (kDw * 4) + (kx[it] - kax[it]), kDw * 4, lane, &m10[it], &m01[it]);
+        for (int it = 1; it < kKpw; it++) phase = (row & 3) == it ? kx[it] - R - kax[it] : phase;
+        const uint32_t aaddr = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t *)wpatch +
+                               (uint32_t)((row & 3) * kPatchBytes + G::kStart + (row >> 2) * 64 + (lane >> 4) * 16 + phase);
+        u32x4 av[G::kMom];
+#pragma unroll
+        for (int ks = 0; ks < G::kMom; ks++) // the waits are per read (in-flight registers never leave an asm block)
+            asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(av[ks]) : "v"(aaddr), "n"(ks * 256) : "memory");
+        v4i acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < G::kMom; ks++) {
+            const uint4 bv = bw[ks];
+            const v4i a = {(int)(av[ks].x ^ 0x80808080u), (int)(av[ks].y ^ 0x80808080u), (int)(av[ks].z ^ 0x80808080u),
+                           (int)(av[ks].w ^ 0x80808080u)};
+            const v4i b = {(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w};
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc, 0, 0, 0);
+        }
+        // D[row][col] sits in lane 16 * (row / 4) + col, register row % 4: keypoint `it`, slice s,
+        // weights xy -> register it of lane 16 s + 2 s + xy
+#pragma unroll
+        for (int it = 0; it < kKpw; it++) {
+#pragma unroll
+            for (int sl = 0; sl < 4; sl++) {
+                m10[it] += __builtin_amdgcn_readlane(acc[it], 18 * sl);
+                m01[it] += __builtin_amdgcn_readlane(acc[it], 18 * sl + 1);
+            }
+        }
     }
     // ---- pass 2: lane `it` owns keypoint `it`
     int lm10 = m10[0], lm01 = m01[0];
@@ -721,9 +815,10 @@ describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__re
         const float a = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(la), it));
         const float b = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(lb), it));
         const int x = kx[it], y = ky[it];
-        const LdsPatch px{reinterpret_cast<const uint8_t *>(s_patch[wv][it]), kDw * 4, y - R, kax[it]};
+        // samples are addressed relative to s_patch: the keypoint's byte offset in it is one constant
         uint64_t d[4] = {0, 0, 0, 0};
-        if (!orb_border_zero(x, y, g.W, g.H, g.angle_in_radians)) orb_describe(px, x, y, a, b, lane, d);
+        if (!orb_border_zero(x, y, g.W, g.H, g.angle_in_radians))
+            orb_describe_lds<G::kPitch>(s_patch, (wv * kKpw + it) * kPatchBytes + R * G::kPitch + x - kax[it], a, b, lane, d);
 
         // every value is wave-uniform: lane 0 stores the 13 dwords of the record
         if (lane == 0) {
@@ -1074,6 +1169,11 @@ int orbfe_create(const orbfe_config *cfg, orbfe_ctx **out)
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_mdesc, B * g.cap * 32);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_mpos, B * g.cap * 8);
     ctx->cap_pad = (g.cap + 15) / 16 * 16;
+    {
+        const std::vector<int8_t> w = make_moment_weights(g.angle_in_radians ? 19 : 15);
+        if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_momw, w.size());
+        if (e == hipSuccess) e = hipMemcpy(ctx->d_momw, w.data(), w.size(), hipMemcpyHostToDevice);
+    }
     if (g.cap <= kMmaMaxKeypoints) { // scratch of the matrix-core matcher
         if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_mexp, B * ctx->cap_pad * 128);
         if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_mkey, B * ctx->cap_pad * sizeof(float));
@@ -1102,6 +1202,7 @@ void orbfe_destroy(orbfe_ctx *ctx)
     if (ctx->d_mpos) (void)hipFree(ctx->d_mpos);
     if (ctx->d_mexp) (void)hipFree(ctx->d_mexp);
     if (ctx->d_mkey) (void)hipFree(ctx->d_mkey);
+    if (ctx->d_momw) (void)hipFree(ctx->d_momw);
     delete ctx;
 }
 
@@ -1244,10 +1345,10 @@ int orbfe_describe_batch(orbfe_ctx *ctx, int n_frames, orbfe_keypoint *d_records
                        ctx->d_selcount, d_counts, so);
     if (g.angle_in_radians)
         hipLaunchKernelGGL(describe_kernel<19>, dim3((g.cap + 4 * kKpw - 1) / (4 * kKpw), n_frames), dim3(256), 0,
-                           S(stream), g, ctx->d_pyr, ctx->d_sel, ctx->d_selcount, d_records, so);
+                           S(stream), g, ctx->d_pyr, ctx->d_sel, ctx->d_selcount, ctx->d_momw, d_records, so);
     else
         hipLaunchKernelGGL(describe_kernel<15>, dim3((g.cap + 4 * kKpw - 1) / (4 * kKpw), n_frames), dim3(256), 0,
-                           S(stream), g, ctx->d_pyr, ctx->d_sel, ctx->d_selcount, d_records, so);
+                           S(stream), g, ctx->d_pyr, ctx->d_sel, ctx->d_selcount, ctx->d_momw, d_records, so);
     CTX_LAUNCH_CHECK(ctx, "describe_batch");
     return ORBFE_OK;
 }

@@ -165,53 +165,6 @@ __device__ inline void patch_moments(const Px &px, int w, int h, int kx, int ky,
     *m01_out = m01;
 }
 
-// The same moments from a patch staged in LDS whose EXCLUDED pixels were zeroed at staging
-// time (rows <= 0 or >= h, columns <= 0 or >= w: exactly the tests of orb.cu:98,112,119), so
-// no per-sample test is left: per row one LDS byte read, one select on the disc chord, two
-// adds; m10 takes its dx factor once at the end.  `centre` points at the keypoint's byte.
-// 64-bit lane mask of the lanes whose column lies inside the disc chord of row dy:
-// lane = column (0..30) + 32 * half, |column - 15| <= u[dy].  A compile-time constant, so the
-// chord test costs one v_cndmask with an SGPR-pair condition instead of a compare per row.
-__host__ __device__ constexpr uint64_t chord_mask(int dy)
-{
-    constexpr int u[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 7, 5, 0};
-    uint64_t m = 0;
-    for (int lane = 0; lane < 64; lane++) {
-        const int col = lane & 31;
-        const int adx = col > 15 ? col - 15 : 15 - col;
-        if (col < 31 && adx <= u[dy]) m |= 1ull << lane;
-    }
-    return m;
-}
-
-__device__ inline void patch_moments_staged(const uint8_t *centre, int pitch_bytes, int lane,
-                                            int *m10_out, int *m01_out)
-{
-    int col = lane & 31;
-    const bool idle = col == 31;
-    col = idle ? 30 : col;
-    const int dx = col - 15;
-    const int step = (lane >> 5) ? pitch_bytes : -pitch_bytes; // half 1 walks down, half 0 up
-    const uint8_t *p = centre + dx;
-    int s = (lane >> 5) ? 0 : (int)p[0]; // centre row belongs to half 0
-    int sy = 0;
-#pragma unroll
-    for (int dy = 1; dy < 16; dy++) {
-        constexpr uint64_t kM[16] = {chord_mask(0),  chord_mask(1),  chord_mask(2),  chord_mask(3),
-                                     chord_mask(4),  chord_mask(5),  chord_mask(6),  chord_mask(7),
-                                     chord_mask(8),  chord_mask(9),  chord_mask(10), chord_mask(11),
-                                     chord_mask(12), chord_mask(13), chord_mask(14), chord_mask(15)};
-        int v = p[dy * step];
-        asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(v) : "v"(v), "s"(kM[dy])); // v = lane in chord ? v : 0
-        s += v;
-        sy += dy * v;
-    }
-    const int m10 = idle ? 0 : dx * s;
-    const int m01 = idle ? 0 : ((lane >> 5) ? sy : -sy);
-    *m10_out = wave_sum_i32(m10);
-    *m01_out = wave_sum_i32(m01);
-}
-
 // ------------------------------------------------------------------------------------
 // rBRIEF (orb.cu:17-75) + 32-bit "compression" (orb.cu:145-169).  One wave per keypoint.
 // In round r (0..3) lane t evaluates pattern test 64 r + t, and the 64-bit __ballot of the
@@ -235,6 +188,35 @@ __device__ inline int rn_plus(float v, int add)
     ORBFE_NO_CONTRACT
     const float r = v + 12582912.0f;
     return (int)__float_as_uint(r) + (add - 0x4B400000);
+}
+
+// rBRIEF from a patch staged in LDS (`bytes` = the LDS array, row pitch PITCH bytes); c0 = byte
+// offset of the keypoint inside it.  Same arithmetic as orb_describe below; only the address of a
+// sample is formed differently, entirely in full-rate f32 ops (integer multiplies by 36 / 44 are
+// quarter rate on this chip): with M = 1.5 * 2^23, row + M and col + M round the coordinates
+// (ties to even, as rn_plus), (row + M) - M is the rounded row as an exact float, and
+// fmaf(row, PITCH, col + M) = M + col + PITCH * row exactly (all integers < 2^22), whose bit
+// pattern is 0x4B400000 + (col + PITCH * row): one integer add gives the LDS byte address.
+template <int PITCH>
+__device__ inline void orb_describe_lds(const uint8_t *bytes, int c0, float a, float b, int lane, uint64_t d[4])
+{
+    ORBFE_NO_CONTRACT
+    const float M = 12582912.0f;
+    const uint32_t cbias = (uint32_t)c0 - 0x4B400000u;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const float4 pt = reinterpret_cast<const float4 *>(c_pattern_f)[64 * r + lane];
+        const float fpx = pt.x, fpy = pt.y, fqx = pt.z, fqy = pt.w;
+        const float p1 = fpx * b, p2 = fpy * a, p3 = fpx * a, p4 = fpy * b;
+        const float q1 = fqx * b, q2 = fqy * a, q3 = fqx * a, q4 = fqy * b;
+        const float prow = (p1 + p2) + M, pcol = (p3 - p4) + M;
+        const float qrow = (q1 + q2) + M, qcol = (q3 - q4) + M;
+        const float pa = __builtin_fmaf(prow - M, (float)PITCH, pcol);
+        const float qa = __builtin_fmaf(qrow - M, (float)PITCH, qcol);
+        const int t0 = bytes[__float_as_uint(pa) + cbias];
+        const int t1 = bytes[__float_as_uint(qa) + cbias];
+        d[r] = __ballot(t0 < t1);
+    }
 }
 
 // (a, b) = (cos, sin) of the steering angle (orb_steer below)

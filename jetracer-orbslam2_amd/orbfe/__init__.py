@@ -14,7 +14,8 @@ import os
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(PKG_DIR, "liborbfe.so")
+# ORBFE_LIB: another build of the same library (A/B timing of kernel variants); still a HIP build, never a fallback
+LIB_PATH = os.environ.get("ORBFE_LIB") or os.path.join(PKG_DIR, "liborbfe.so")
 
 OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE, ERR_CAPACITY = range(6)
 SUM_OF_ABS_DIFF_ALL, SUM_OF_ABS_DIFF_ON_ARC, MAX_THRESHOLD = 0, 1, 2
