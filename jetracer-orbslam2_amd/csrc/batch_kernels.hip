@@ -126,16 +126,30 @@ pyramid_fused_kernel(DeviceGeom g, uint8_t *__restrict__ pyr, const uint8_t *__r
     const uint32_t M = 0x00FF00FFu;
     const bool seam_l = (cx & 7) == 0, seam_r = (cx & 7) == 7 || x0 + 4 >= W;
 
+    // Gray source: the 18 input rows of this thread (y - 1 .. y + 16) are loaded up front, all in
+    // flight together.  The loads are unconditional (addresses clamped into the frame, values masked
+    // afterwards): a conditional load cannot be hoisted, and with one load + s_waitcnt vmcnt(0) per
+    // row (which also waits for the previous row's stores) a wave had one request in flight.
+    uint32_t rowv[18];
+    if (!RGB) {
+        const int xc = col_ok ? x0 : 0;
+#pragma unroll
+        for (int k = 0; k < 18; k++) {
+            int yy = ybase - 1 + k;
+            yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+            rowv[k] = *reinterpret_cast<const uint32_t *>(src + (size_t)yy * src_pitch + xc);
+        }
+    }
     // horizontal 1-2-1 sums of input row yy, as (even pixels, odd pixels) 16-bit lane pairs
-    auto hrow = [&](int yy, uint32_t &hE, uint32_t &hO) {
+    auto hrow = [&](int yy, int k, uint32_t &hE, uint32_t &hO) {
         uint32_t v = 0;
-        if (col_ok && yy >= 0 && yy < H) {
-            if (RGB) {
+        if (RGB) {
+            if (col_ok && yy >= 0 && yy < H) {
                 const uint32_t *p3 = reinterpret_cast<const uint32_t *>(src + (size_t)yy * src_pitch + 3 * x0);
                 v = rgb4_to_gray4(p3[0], p3[1], p3[2]);
-            } else {
-                v = *reinterpret_cast<const uint32_t *>(src + (size_t)yy * src_pitch + x0);
             }
+        } else {
+            v = (col_ok && yy >= 0 && yy < H) ? rowv[k] : 0u;
         }
         const uint32_t Ld = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true); // lane - 1
         const uint32_t Rd = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xF, 0xF, true); // lane + 1
@@ -147,15 +161,15 @@ pyramid_fused_kernel(DeviceGeom g, uint8_t *__restrict__ pyr, const uint8_t *__r
     };
 
     uint32_t aE, aO, bE, bO, cE, cO; // h of rows y-1, y, y+1
-    hrow(ybase - 1, aE, aO);
-    hrow(ybase, bE, bO);
+    hrow(ybase - 1, 0, aE, aO);
+    hrow(ybase, 1, bE, bO);
     uint32_t prev_s = 0;  // level-0 pair sums of the previous (even) row
     uint32_t prev_l1 = 0; // level-1 row of the previous row pair
     const bool want1 = g.L > 1, want2 = g.L > 2;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int y = ybase + r;
-        hrow(y + 1, cE, cO);
+        hrow(y + 1, r + 2, cE, cO);
         uint32_t oE = ((aE + 2u * bE + cE + 0x00080008u) >> 4) & M;
         uint32_t oO = ((aO + 2u * bO + cO + 0x00080008u) >> 4) & M;
         if (y == 0 || y >= H - 2) { // rows the reference never writes (Q1)
