@@ -349,26 +349,45 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
         int r = tid / kPxDw, q = tid - r * kPxDw;
         uint32_t off = (uint32_t)(__mul24(y0 - 4 + r, P) + x0 - 4 + 4 * q); // wraps harmlessly when unused
         const uint32_t dstep = (uint32_t)((256 / kPxDw) * P + 4 * (256 % kPxDw));
+        constexpr int kLoadTrips = (kPxH * kPxDw + 255) / 256;
+        if (all_in) {
+            // interior tile: every load is unconditional, so all kLoadTrips requests of a thread are in
+            // flight together (a conditional load is followed by its own s_waitcnt vmcnt(0): six memory
+            // latencies in a row).  Lanes past the tile's last dword re-load their first one.
+            uint32_t v[kLoadTrips];
+            const uint32_t off0 = off;
 #pragma unroll
-        for (int i0 = 0; i0 < kPxH * kPxDw; i0 += 256) {
-            const int i = i0 + tid;
-            if (i0 + 256 <= kPxH * kPxDw || i < kPxH * kPxDw) {
-                uint32_t v = 0;
-                if (all_in) {
-                    v = *reinterpret_cast<const uint32_t *>(img + off);
-                } else {
+            for (int t = 0; t < kLoadTrips; t++) {
+                const bool in = 256 * (t + 1) <= kPxH * kPxDw || 256 * t + tid < kPxH * kPxDw;
+                v[t] = *reinterpret_cast<const uint32_t *>(img + (in ? off : off0));
+                off += dstep;
+                q += 256 % kPxDw;
+                if (q >= kPxDw) { // carry into the next row
+                    q -= kPxDw;
+                    off += (uint32_t)(P - 4 * kPxDw);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < kLoadTrips; t++)
+                if (256 * (t + 1) <= kPxH * kPxDw || 256 * t + tid < kPxH * kPxDw) s_px32[256 * t + tid] = v[t];
+        } else {
+#pragma unroll
+            for (int i0 = 0; i0 < kPxH * kPxDw; i0 += 256) {
+                const int i = i0 + tid;
+                if (i0 + 256 <= kPxH * kPxDw || i < kPxH * kPxDw) {
+                    uint32_t v = 0;
                     const int gy = y0 - 4 + r, gx = x0 - 4 + 4 * q;
                     if (gy >= 0 && gy < H && gx >= 0 && gx < P) v = *reinterpret_cast<const uint32_t *>(img + off);
+                    s_px32[i] = v;
                 }
-                s_px32[i] = v;
-            }
-            off += dstep;
-            r += 256 / kPxDw;
-            q += 256 % kPxDw;
-            if (q >= kPxDw) { // carry into the next row
-                q -= kPxDw;
-                r += 1;
-                off += (uint32_t)(P - 4 * kPxDw);
+                off += dstep;
+                r += 256 / kPxDw;
+                q += 256 % kPxDw;
+                if (q >= kPxDw) { // carry into the next row
+                    q -= kPxDw;
+                    r += 1;
+                    off += (uint32_t)(P - 4 * kPxDw);
+                }
             }
         }
         static_assert((kScH * kScPitch * 2) % 16 == 0, "score tile is zeroed with 16-byte stores");
