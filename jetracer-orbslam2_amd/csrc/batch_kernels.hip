@@ -723,10 +723,14 @@ describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__re
     const int P = g.lv[0].pitch;
     const uint4 *fsel = sel + (size_t)f * g.cap + slot0;
     uint8_t *wpatch = s_patch + wv * (kKpw * kPatchBytes); // this wave's kKpw patches
-    // weight fragments of the moment MFMAs: issued first, they arrive under the patch staging
+    // weight fragments of the moment MFMAs and this lane's four rBRIEF pattern rows (the same for
+    // every keypoint): issued first, they arrive under the patch staging
     uint4 bw[G::kMom];
 #pragma unroll
     for (int ks = 0; ks < G::kMom; ks++) bw[ks] = momw[ks * 64 + lane];
+    float4 pat[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) pat[r] = reinterpret_cast<const float4 *>(c_pattern_f)[64 * r + lane];
 
     int kx[kKpw], ky[kKpw], kax[kKpw], m10[kKpw], m01[kKpw];
     uint32_t kcell[kKpw], kkey[kKpw];
@@ -851,7 +855,7 @@ describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__re
         // samples are addressed relative to s_patch: the keypoint's byte offset in it is one constant
         uint64_t d[4] = {0, 0, 0, 0};
         if (!orb_border_zero(x, y, g.W, g.H, g.angle_in_radians))
-            orb_describe_lds<G::kPitch>(s_patch, (wv * kKpw + it) * kPatchBytes + R * G::kPitch + x - kax[it], a, b, lane, d);
+            orb_describe_lds<G::kPitch>(s_patch, (wv * kKpw + it) * kPatchBytes + R * G::kPitch + x - kax[it], a, b, pat, d);
 
         // every value is wave-uniform: lane 0 stores the 13 dwords of the record
         if (lane == 0) {

@@ -197,15 +197,18 @@ __device__ inline int rn_plus(float v, int add)
 // (ties to even, as rn_plus), (row + M) - M is the rounded row as an exact float, and
 // fmaf(row, PITCH, col + M) = M + col + PITCH * row exactly (all integers < 2^22), whose bit
 // pattern is 0x4B400000 + (col + PITCH * row): one integer add gives the LDS byte address.
+// pat[r] = pattern row 64 r + lane (the caller loads the four rows once per wave: they are the same
+// for every keypoint).
 template <int PITCH>
-__device__ inline void orb_describe_lds(const uint8_t *bytes, int c0, float a, float b, int lane, uint64_t d[4])
+__device__ inline void orb_describe_lds(const uint8_t *bytes, int c0, float a, float b, const float4 (&pat)[4],
+                                        uint64_t d[4])
 {
     ORBFE_NO_CONTRACT
     const float M = 12582912.0f;
     const uint32_t cbias = (uint32_t)c0 - 0x4B400000u;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const float4 pt = reinterpret_cast<const float4 *>(c_pattern_f)[64 * r + lane];
+        const float4 pt = pat[r];
         const float fpx = pt.x, fpy = pt.y, fqx = pt.z, fqy = pt.w;
         const float p1 = fpx * b, p2 = fpy * a, p3 = fpx * a, p4 = fpy * b;
         const float q1 = fqx * b, q2 = fqy * a, q3 = fqx * a, q4 = fqy * b;
