@@ -742,13 +742,18 @@ describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__re
         const int c = 64 * t + lane, r = c / G::kChunksRow;
         voff[t] = (uint32_t)(__mul24(r, P) + G::kChunk * (c - r * G::kChunksRow));
     }
+    // the wave's selection entries: uniform addresses = scalar loads, all four issued before the first
+    // use (behind the uniform `it >= nk` test each would be followed by its own wait)
+    uint4 srs[kKpw];
+#pragma unroll
+    for (int it = 0; it < kKpw; it++) srs[it] = fsel[it < nk ? it : nk - 1];
     // ---- pass 1: stage + moments
 #pragma unroll
     for (int it = 0; it < kKpw; it++) {
         kx[it] = ky[it] = kax[it] = m10[it] = m01[it] = 0;
         kcell[it] = kkey[it] = 0;
         if (it >= nk) continue; // uniform
-        const uint4 sr = fsel[it]; // uniform address: scalar load
+        const uint4 sr = srs[it];
         kcell[it] = sr.x;
         kkey[it] = sr.z;
         const int x = (int)(sr.y & 0xFFFFu), y = (int)(sr.y >> 16);
