@@ -126,30 +126,28 @@ pyramid_fused_kernel(DeviceGeom g, uint8_t *__restrict__ pyr, const uint8_t *__r
     const uint32_t M = 0x00FF00FFu;
     const bool seam_l = (cx & 7) == 0, seam_r = (cx & 7) == 7 || x0 + 4 >= W;
 
-    // Gray source: the 18 input rows of this thread (y - 1 .. y + 16) are loaded up front, all in
+    // The 18 input rows of this thread (y - 1 .. y + 16; RGB: three dwords each) are loaded up front, all in
     // flight together.  The loads are unconditional (addresses clamped into the frame, values masked
     // afterwards): a conditional load cannot be hoisted, and with one load + s_waitcnt vmcnt(0) per
     // row (which also waits for the previous row's stores) a wave had one request in flight.
-    uint32_t rowv[18];
-    if (!RGB) {
+    uint32_t rowv[18][RGB ? 3 : 1];
+    {
         const int xc = col_ok ? x0 : 0;
 #pragma unroll
         for (int k = 0; k < 18; k++) {
             int yy = ybase - 1 + k;
             yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
-            rowv[k] = *reinterpret_cast<const uint32_t *>(src + (size_t)yy * src_pitch + xc);
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(src + (size_t)yy * src_pitch + (RGB ? 3 : 1) * xc);
+#pragma unroll
+            for (int j = 0; j < (RGB ? 3 : 1); j++) rowv[k][j] = p[j];
         }
     }
     // horizontal 1-2-1 sums of input row yy, as (even pixels, odd pixels) 16-bit lane pairs
     auto hrow = [&](int yy, int k, uint32_t &hE, uint32_t &hO) {
         uint32_t v = 0;
-        if (RGB) {
-            if (col_ok && yy >= 0 && yy < H) {
-                const uint32_t *p3 = reinterpret_cast<const uint32_t *>(src + (size_t)yy * src_pitch + 3 * x0);
-                v = rgb4_to_gray4(p3[0], p3[1], p3[2]);
-            }
-        } else {
-            v = (col_ok && yy >= 0 && yy < H) ? rowv[k] : 0u;
+        if (col_ok && yy >= 0 && yy < H) {
+            if constexpr (RGB) v = rgb4_to_gray4(rowv[k][0], rowv[k][1], rowv[k][2]);
+            else v = rowv[k][0];
         }
         const uint32_t Ld = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true); // lane - 1
         const uint32_t Rd = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xF, 0xF, true); // lane + 1
