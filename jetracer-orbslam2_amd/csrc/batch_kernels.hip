@@ -535,7 +535,6 @@ select_kernel(DeviceGeom g, const uint32_t *__restrict__ cellkey, uint4 *__restr
     constexpr int kBinsPer = 4096 / kSelThreads; // score bins owned by one thread
     __shared__ uint32_t s_hist[4096];
     __shared__ int s_wave[kSelWaves];
-    __shared__ int s_tot[kSelThreads];
     __shared__ int s_thr, s_quota;
     const int f = blockIdx.x, tid = threadIdx.x;
     const uint32_t *keys = cellkey + (size_t)f * g.K;
@@ -544,27 +543,45 @@ select_kernel(DeviceGeom g, const uint32_t *__restrict__ cellkey, uint4 *__restr
         s_thr = 0;          // keep score > s_thr ...
         s_quota = 0;        // ... plus the first s_quota cells with score == s_thr
     }
+    // The frame's cell keys are read twice (histogram, compaction): the first kKeyRegs trips are
+    // loaded once, unconditionally (index clamped, value masked), so that all of a thread's requests
+    // are in flight together instead of one load + wait per trip; larger grids read the rest twice.
+    constexpr int kKeyRegs = 8; // 8192 cells; 640x480 with 8-px cells has 4800
+    uint32_t kreg[kKeyRegs];
+#pragma unroll
+    for (int t = 0; t < kKeyRegs; t++) {
+        const int k = t * kSelThreads + tid;
+        const uint32_t v = keys[k < g.K ? k : g.K - 1];
+        kreg[t] = k < g.K ? v : 0u;
+    }
     if (g.max_features > 0) {
         for (int i = tid; i < 4096; i += kSelThreads) s_hist[i] = 0u;
         __syncthreads();
-        for (int k = tid; k < g.K; k += kSelThreads) {
+#pragma unroll
+        for (int t = 0; t < kKeyRegs; t++) {
+            const uint32_t s = kreg[t] >> 15;
+            if (s) atomicAdd(&s_hist[s], 1u);
+        }
+        for (int k = kKeyRegs * kSelThreads + tid; k < g.K; k += kSelThreads) {
             const uint32_t s = keys[k] >> 15;
             if (s) atomicAdd(&s_hist[s], 1u);
         }
         __syncthreads();
-        // thread t owns bins kBinsPer * t ...; `above` = how many scores lie in higher bins
+        // thread t owns bins kBinsPer * t ...; `above` = how many scores lie in higher bins:
+        // total - inclusive prefix over threads (DPP wave scan + one cross-wave step)
         int mine = 0;
         for (int b = 0; b < kBinsPer; b++) mine += (int)s_hist[kBinsPer * tid + b];
-        s_tot[tid] = mine;
+        const int incl = wave_incl_scan_i32(mine);
+        if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
         __syncthreads();
-        // suffix sum over threads: in-place Hillis-Steele on s_tot (log2(1024) = 10 steps)
-        for (int d = 1; d < kSelThreads; d <<= 1) {
-            const int v = tid + d < kSelThreads ? s_tot[tid + d] : 0;
-            __syncthreads();
-            s_tot[tid] += v;
-            __syncthreads();
+        int wave_off = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kSelWaves; w++) {
+            const int v = s_wave[w];
+            wave_off += w < (tid >> 6) ? v : 0;
+            total += v;
         }
-        int above = s_tot[tid] - mine; // scores in bins owned by higher threads
+        int above = total - (wave_off + incl); // scores in bins owned by higher threads
         for (int b = kBinsPer - 1; b >= 0; b--) {
             const int n = (int)s_hist[kBinsPer * tid + b];
             if (above < g.max_features && above + n >= g.max_features && n > 0) {
@@ -581,7 +598,14 @@ select_kernel(DeviceGeom g, const uint32_t *__restrict__ cellkey, uint4 *__restr
     for (int base = 0; base < g.K; base += kSelThreads) {
         const int k = base + tid;
         const bool in = k < g.K;
-        const uint32_t key = in ? keys[k] : 0u;
+        const int trip = base / kSelThreads;
+        uint32_t key = 0u;
+        if (trip < kKeyRegs) { // static after unrolling
+#pragma unroll
+            for (int t = 0; t < kKeyRegs; t++) key = t == trip ? kreg[t] : key;
+        } else if (in) {
+            key = keys[k];
+        }
         const int score = (int)(key >> 15);
         const bool tie = in && thr > 0 && score == thr;
         int tie_tot;
