@@ -110,13 +110,20 @@ halfsample_batch_kernel(uint8_t *__restrict__ pyr, size_t fstride, size_t src_of
 template <bool RGB>
 __global__ void __launch_bounds__(256)
 pyramid_fused_kernel(DeviceGeom g, uint8_t *__restrict__ pyr, const uint8_t *__restrict__ src, int src_pitch,
-                     size_t src_fstride, int tiles_x)
+                     size_t src_fstride, int tiles_x, uint32_t *__restrict__ cellkey)
 {
     __shared__ uint8_t s_l2[32 * 32], s_l3[16 * 16], s_l4[8 * 8], s_l5[4 * 4], s_l6[2 * 2];
     int f, tile;
     xcd_remap(gridDim.x, gridDim.y, &f, &tile);
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int tid = threadIdx.x, cx = tid & 31, rg = tid >> 5;
+    // by-product: the frame's cell keys are cleared for the detection that follows (saves the
+    // memset launch of detect_batch); tile t clears the t-th slice
+    {
+        const int per = (g.K + (int)gridDim.x - 1) / (int)gridDim.x;
+        const int hi = (tile + 1) * per < g.K ? (tile + 1) * per : g.K;
+        for (int i = tile * per + tid; i < hi; i += 256) cellkey[(size_t)f * g.K + i] = 0u;
+    }
     const int W = g.W, H = g.H;
     const int x0 = tx * 128 + 4 * cx;
     const int ybase = ty * 128 + rg * 16;
@@ -1303,15 +1310,17 @@ static int build_pyramid_impl(orbfe_ctx *ctx, const uint8_t *d_src, size_t pitch
         CTX_FAIL(ctx, ORBFE_ERR_UNSUPPORTED, "build_pyramid_rgb: needs width %% 4 == 0 and a 4-byte aligned source "
                  "(use orbfe_rgb_to_grayscale + orbfe_build_pyramid otherwise)");
     int next_level = 1; // first level still to be produced by the unfused halving kernel
+    ctx->cellkey_clean = 0;
     if (vec && g.W % 4 == 0) {
         const int tiles_x = (g.W + 127) / 128, tiles_y = (g.H + 127) / 128;
         if (rgb)
             hipLaunchKernelGGL(pyramid_fused_kernel<true>, dim3(tiles_x * tiles_y, n_frames), dim3(256), 0, S(stream),
-                               g, ctx->d_pyr, d_src, (int)pitch, frame_stride, tiles_x);
+                               g, ctx->d_pyr, d_src, (int)pitch, frame_stride, tiles_x, ctx->d_cellkey);
         else
             hipLaunchKernelGGL(pyramid_fused_kernel<false>, dim3(tiles_x * tiles_y, n_frames), dim3(256), 0, S(stream),
-                               g, ctx->d_pyr, d_src, (int)pitch, frame_stride, tiles_x);
+                               g, ctx->d_pyr, d_src, (int)pitch, frame_stride, tiles_x, ctx->d_cellkey);
         next_level = 8;
+        ctx->cellkey_clean = n_frames; // the fused kernel cleared these frames' cell keys (same stream order)
     } else {
         dim3 grid(((g.W + 255) / 256) * ((g.H + 3) / 4), n_frames), block(256);
         if (vec)
@@ -1355,7 +1364,9 @@ int orbfe_detect_batch_shard(orbfe_ctx *ctx, int n_frames, int shard_index, int 
         CTX_FAIL(ctx, ORBFE_ERR_CAPACITY, "detect_batch: n_frames %d > max_batch %d", n_frames, ctx->cfg.max_batch);
     const DeviceGeom &g = ctx->g;
     ORBFE_HIP_TRY(ctx->err, hipSetDevice(ctx->cfg.device));
-    ORBFE_HIP_TRY(ctx->err, hipMemsetAsync(ctx->d_cellkey, 0, (size_t)n_frames * g.K * sizeof(uint32_t), S(stream)));
+    if (ctx->cellkey_clean < n_frames) // not cleared by the pyramid kernel that just ran, or already used
+        ORBFE_HIP_TRY(ctx->err, hipMemsetAsync(ctx->d_cellkey, 0, (size_t)n_frames * g.K * sizeof(uint32_t), S(stream)));
+    ctx->cellkey_clean = 0;
     // tiles shard_index, shard_index + shard_count, ... (interleaved: every shard gets a mix of
     // levels and of busy / empty image regions)
     const int n_mine = ctx->n_tiles > shard_index ? (ctx->n_tiles - shard_index + shard_count - 1) / shard_count : 0;

@@ -164,6 +164,7 @@ struct orbfe_ctx {
     uint4 *d_mexp = nullptr;        // [max_batch][cap_pad][8]  MFMA matcher: descriptors as e2m1 fragments (cap <= 16384)
     float *d_mkey = nullptr;        // [max_batch][cap_pad]     MFMA matcher: -(popcount * 16384 + index)
     int cap_pad = 0;                // cap rounded up to 16
+    int cellkey_clean = 0;          // frames whose cell keys the last pyramid build left cleared (0 once detect ran)
     uint4 *d_momw = nullptr;        // describe: int8 weight fragments of the moment MFMAs (make_moment_weights)
     orbfe::TileDesc *d_tiles = nullptr;
     int n_tiles = 0;
