@@ -50,3 +50,21 @@ e1.record()
 torch.cuda.synchronize()
 print("stage API, %dx%d, %d level(s), K = %d: %.1f us per frame (%d keypoints)"
       % (w, h, levels, k, e0.elapsed_time(e1) / n * 1e3, int((grid[2 * k:3 * k] > 0).sum())))
+
+# the same frame through the batch API with a batch of one (orbfe_extract = 4 launches), and the
+# 8-level / 2000-feature regime of the bench
+for tag, cfg in (("reference regime", dict(levels=levels, cell=32, min_arc=12)),
+                 ("bench regime", dict(levels=8, cell=8, min_arc=9, max_features=2000))):
+    ctx = orbfe.Context(w, h, max_batch=1, **cfg)
+    rec = torch.zeros(ctx.cap * 52, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for _ in range(20):
+        ctx.extract(gray.data_ptr(), w, w * h, 1, rec.data_ptr(), cnt.data_ptr(), None, s)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        ctx.extract(gray.data_ptr(), w, w * h, 1, rec.data_ptr(), cnt.data_ptr(), None, s)
+    e1.record()
+    torch.cuda.synchronize()
+    print("batch API, batch of 1, %s: %.1f us per frame (%d keypoints)"
+          % (tag, e0.elapsed_time(e1) / n * 1e3, int(cnt.item())))
