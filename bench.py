@@ -5,9 +5,11 @@
 
 One "step" = one pass of the hot path over one batch of synthetic frames already resident
 in HBM: orbfe_extract (blur + pyramid -> fused FAST/NMS -> selection -> orientation + rBRIEF
--> 52-byte records) followed by orbfe_match_batch (frame t-1 -> t inside the batch) and, for
-N > 1, the gather of keypoint records to rank 0 (RCCL).  Frames shard across ranks (weak
-scaling: --batch frames per GPU).  Rank 0 prints ONE JSON line.
+-> 52-byte records) followed by orbfe_match_batch (frame t-1 -> t inside the batch).  Frames are
+independent, so for N > 1 they shard across ranks (weak scaling: --batch frames per GPU) and
+the data path has no collective; RCCL carries only the barrier and the final reductions of the
+timing.  --gather adds the optional collection of every rank's records on rank 0 (RCCL gather,
+asynchronous, overlapped with the next step).  Rank 0 prints ONE JSON line.
 
 Workload (BASELINE.json configs[1]): 640x480 mono, 8-level pyramid, 2000 features/frame.
 In this code base that is: cell 8 (4800 cells, detection on levels 0..3 where the cell is
@@ -106,6 +108,10 @@ def main():
     ap.add_argument("--rgb", action="store_true",
                     help="feed interleaved RGB8 frames (SURVEY.md 8f-1): the gray conversion is fused into "
                          "the pyramid kernel; not the BASELINE metric (its configs are grayscale)")
+    ap.add_argument("--gather", action="store_true",
+                    help="N > 1: also gather every rank's keypoint records to rank 0 each step (asynchronous, "
+                         "double-buffered).  Off by default: the frames are independent and the path has no "
+                         "exchange step (26.6 MB per rank and step would ride on one xGMI link each)")
     ap.add_argument("--stage-iters", type=int, default=10, help="(unused; kept for old command lines)")
     args = ap.parse_args()
 
@@ -158,7 +164,8 @@ def main():
     s = torch.cuda.current_stream().cuda_stream
     mm = m["match"]
     gather_out = None
-    if world > 1 and rank == 0:
+    do_gather = world > 1 and args.gather
+    if do_gather and rank == 0:
         gather_out = [(torch.empty((world, B * ctx.cap * 52), dtype=torch.uint8, device=dev),
                        torch.empty((world, B), dtype=torch.int32, device=dev)) for _ in range(2)]
     pending = [None, None]
@@ -192,7 +199,7 @@ def main():
         if ev:
             ev[4].record()
             stage_events.append(ev)
-        if world > 1:
+        if do_gather:
             pending[b] = gather_keypoints_async(r, c, gather_out[b] if gather_out else None, dst=0)
 
     def drain():
@@ -286,8 +293,9 @@ def main():
             "config": {"workload": m["workload"] + (" [RGB8 input, conversion fused]" if args.rgb else ""),
                        "frames_per_gpu_per_step": B,
                        "frames_per_step": B * world, "keypoints_per_frame": k_out,
-                       "collective": "async gather of 52-byte keypoint records to rank 0, overlapped with the "
-                                     "next step" if world > 1 else "none"},
+                       "collective": ("async gather of 52-byte keypoint records to rank 0, overlapped with the "
+                                      "next step" if do_gather else
+                                      "none in the data path (independent frames); barrier + timing reductions only")},
             "frames_per_s": B * world * args.steps / elapsed,
             "matcher_gpairs_per_s": pairs_local / (ms_match * 1e-3) / 1e9,
             "matcher_pairs_per_step": pairs_total,
