@@ -310,8 +310,10 @@ def main():
                                  "(DESIGN.md section 4), so frac stays small by construction",
                          "stages": per_stage},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(base, args.mode)
+        elif world > 1:
+            out["cpu_baseline"] = None
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
