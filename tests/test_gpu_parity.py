@@ -513,6 +513,44 @@ def test_match_batch_256_crafted_records(gpu, oracle_mod, w, h, kw, maxd):
     assert torch.equal(d_idx, d_idx2)
 
 
+@pytest.mark.parametrize("w,h,kw", [(100, 70, dict(cell=8)), (640, 480, dict(cell=16)),
+                                    (640, 480, dict(cell=8, max_features=2000))])
+def test_match_batch_256_ragged_counts_fuzz(gpu, oracle_mod, w, h, kw):
+    """Random keypoint counts per frame (0 .. cap, many small ones): every wave of the matrix-core
+    matcher sees 0, 1, 2, ... candidate blocks, so all tails of its 4-slot LDS ring are exercised;
+    descriptors are drawn from a small pool so that exact ties are frequent."""
+    torch, orbfe = gpu
+    n = 12
+    ctx = orbfe.Context(w, h, max_batch=n, **kw)
+    cap = ctx.cap
+    rng = np.random.default_rng(cap + 7)
+    for trial in range(6):
+        small = rng.integers(0, min(cap, 200) + 1, n)
+        big = rng.integers(0, cap + 1, n)
+        counts = np.where(rng.random(n) < 0.5, small, big).astype(np.int32)
+        counts[rng.integers(0, n)] = cap
+        pool = rng.integers(0, 256, (64, 32), dtype=np.uint8)
+        rec = np.zeros((n, cap), orbfe.KEYPOINT_DTYPE)
+        rec["desc"] = rng.integers(0, 256, (n, cap, 32), dtype=np.uint8)
+        dup = rng.random((n, cap)) < 0.3
+        rec["desc"][dup] = pool[rng.integers(0, 64, int(dup.sum()))]
+        maxd = int(rng.choice([256, 120, 40, 0]))
+        d_rec = dev(torch, rec.view(np.uint8).reshape(-1))
+        d_cnt = dev(torch, counts)
+        d_idx = torch.full(((n - 1) * cap,), -7, dtype=torch.int32, device="cuda")
+        d_dist = torch.full(((n - 1) * cap,), -7, dtype=torch.int32, device="cuda")
+        ctx.match_batch(d_rec.data_ptr(), d_cnt.data_ptr(), n, 1, -1, maxd, d_idx.data_ptr(), d_dist.data_ptr(),
+                        stream(torch))
+        idx = d_idx.cpu().numpy().reshape(n - 1, cap)
+        dist = d_dist.cpu().numpy().reshape(n - 1, cap)
+        for p in range(n - 1):
+            A, B = rec[p, :counts[p]], rec[p + 1, :counts[p + 1]]
+            ref_idx, ref_dist = oracle_mod.match256(A["desc"], B["desc"], None, None, -1, maxd)
+            np.testing.assert_array_equal(idx[p, :counts[p]], ref_idx, err_msg="trial %d pair %d" % (trial, p))
+            np.testing.assert_array_equal(dist[p, :counts[p]], ref_dist)
+            assert (idx[p, counts[p]:] == -1).all()
+
+
 @pytest.mark.parametrize("maxf,path", [(16384, "matrix cores, index uses all 14 bits"),
                                        (16400, "VALU kernel: more than 16384 keypoints per frame")])
 def test_match_batch_256_at_the_key_packing_limit(gpu, oracle_mod, maxf, path):
