@@ -1,49 +1,114 @@
 #!/usr/bin/env python3
 """bench.py -- ORB front-end throughput on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--mode c2|ref]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode c2|ref|c3|c4|c5] [--scene dense|survey]
 
-One "step" = one pass of the hot path over one batch of synthetic frames already resident
-in HBM: orbfe_extract (blur + pyramid -> fused FAST/NMS -> selection -> orientation + rBRIEF
--> 52-byte records) followed by orbfe_match_batch (frame t-1 -> t inside the batch).  Frames are
-independent, so for N > 1 they shard across ranks (weak scaling: --batch frames per GPU) and
-the data path has no collective; RCCL carries only the barrier and the final reductions of the
-timing.  --gather adds the optional collection of every rank's records on rank 0 (RCCL gather,
-asynchronous, overlapped with the next step).  Rank 0 prints ONE JSON line.
+One "step" = one pass of the hot path over one batch of synthetic frames already resident in HBM:
+orbfe_extract (blur + pyramid -> fused FAST/NMS -> selection -> orientation + rBRIEF -> 52-byte
+records) followed by the Hamming matcher.  Rank 0 prints ONE JSON line.
 
-Workload (BASELINE.json configs[1]): 640x480 mono, 8-level pyramid, 2000 features/frame.
-In this code base that is: cell 8 (4800 cells, detection on levels 0..3 where the cell is
->= 1 px), FAST-9 with t = 13, top-2000 by (score desc, cell asc), 256-bit brute-force
-matching.  --mode ref runs the reference-parity configuration instead (cell 32, FAST-12,
-6 levels, <= 300 keypoints/frame, 32-bit windowed matcher) -- a parity case, not the metric.
+Modes (BASELINE.json configs):
+  c2   configs[1], the metric: 640x480 mono, 8-level pyramid, 2000 features/frame; here cell 8
+       (4800 cells, detection on levels 0..3), FAST-9 t = 13, top-2000 by (score desc, cell asc),
+       256-bit brute-force matching t-1 -> t; 256 frames per GPU per step (weak scaling).
+  ref  the reference-parity configuration (cell 32, FAST-12, 6 levels, <= 300 keypoints, 32-bit
+       windowed matcher) -- a parity case, not the metric.
+  c3   configs[2]: RealSense-shaped stereo 848x480 pairs (right = left shifted 3 px + noise),
+       extract both + windowed 256-bit match left -> right; 128 pairs per GPU per step.
+  c4   configs[3]: 64 frames 1280x720 in total, sharded over the ranks (strong scaling), records
+       gathered on rank 0.
+  c5   configs[4]: ONE 3840x2160 frame, 12 levels, 8000 features; detection tiles sharded over the
+       ranks, per-cell keys merged by all-reduce(MAX), then selection + description.
+
+Multi-GPU: one process per GPU.  Under torchrun (WORLD_SIZE set) this process is one rank; with
+--gpus N > 1 and no WORLD_SIZE the parent starts N child ranks itself BEFORE touching the GPU and
+relays rank 0's line.  The timed region at N > 1 ends when the keypoint gather is complete on
+rank 0: records and counts travel through liborbfe_dist.so (C++ host code on RCCL:
+grouped ncclSend / ncclRecv on its own stream, overlapped with the next step's kernels).  The
+rate without the gather is reported beside it as `no_gather`.
 
 Only the cpu_baseline leg imports oracle/ (the CPU restatement, timed as a baseline).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "jetracer-orbslam2_amd"))
 
+EXT = dict(levels=8, cell=8, min_arc=9, max_features=2000)
 MODES = {
-    "c2": dict(width=640, height=480, cfg=dict(levels=8, cell=8, min_arc=9, max_features=2000),
-               match=dict(mode=1, window=-1, max_distance=256),
-               workload="640x480 mono, 8-level pyramid, 2000 features/frame (cell 8, FAST-9 t=13, "
-                        "top-2000), 256-bit brute-force match t-1->t"),
+    "c2": dict(width=640, height=480, cfg=EXT, match=dict(mode=1, window=-1, max_distance=256), batch=256, stride=1,
+               scaling="weak",
+               workload="640x480 mono, 8-level pyramid, 2000 features/frame (cell 8, FAST-9 t=13, top-2000), "
+                        "256-bit brute-force match t-1->t"),
     "ref": dict(width=640, height=480, cfg=dict(levels=6, cell=32, min_arc=12, max_features=0),
-                match=dict(mode=0, window=2, max_distance=4),
-                workload="640x480 mono, reference-parity mode (6 levels, cell 32, FAST-12 t=13, "
-                         "<=300 keypoints), 32-bit windowed match t-1->t"),
+                match=dict(mode=0, window=2, max_distance=4), batch=256, stride=1, scaling="weak",
+                workload="640x480 mono, reference-parity mode (6 levels, cell 32, FAST-12 t=13, <=300 keypoints), "
+                         "32-bit windowed match t-1->t"),
+    "c3": dict(width=848, height=480, cfg=EXT, match=dict(mode=1, window=16, max_distance=64), batch=256, stride=2,
+               scaling="weak",
+               workload="848x480 stereo pairs (right = left shifted 3 px, +-2 noise), 8 levels, 2000 features/frame, "
+                        "256-bit match left->right within +-16 px, distance <= 64"),
+    "c4": dict(width=1280, height=720, cfg=EXT, match=dict(mode=1, window=-1, max_distance=256), batch=64, stride=1,
+               scaling="strong",
+               workload="64 frames 1280x720 in total sharded over the ranks, 8 levels, 2000 features/frame, 256-bit "
+                        "brute-force match t-1->t, keypoint records gathered on rank 0"),
+    "c5": dict(width=3840, height=2160, cfg=dict(levels=12, cell=16, min_arc=9, max_features=8000),
+               match=None, batch=1, stride=1, scaling="strong",
+               workload="one 3840x2160 frame, 12-level pyramid, 8000 features (cell 16, FAST-9, top-8000); detection "
+                        "tiles sharded over the ranks, cell keys merged by all-reduce(MAX), then describe"),
 }
 FP4_MFMA_PEAK_TFLOPS = 10000.0
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+# vector ALU: 256 CUs x 4 SIMDs x 32 lanes per clock at 2.4 GHz (the chip's 157.3 TFLOP/s fp32 / 2);
+# full-rate instructions measure 58-64 T lane-ops/s under load (tools/valu_rate*.hip)
+VALU_PEAK_TLANEOPS = 78.6
 
 
+# --------------------------------------------------------------------------------------------
+# launching N ranks from one command line (no torch / GPU call may precede this)
+# --------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def child_commands(args, argv):
+    """The N child (argv, env-additions) this parent starts for --gpus N."""
+    port = int(os.environ.get("MASTER_PORT", "0")) or _free_port()
+    out = []
+    for r in range(args.gpus):
+        env = {"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
+               "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0",
+               "ORBFE_BENCH_CHILD": "1"}
+        out.append(([sys.executable, os.path.abspath(__file__)] + [a for a in argv if a != "--dry-run"], env))
+    return out
+
+
+def spawn_ranks(args, argv):
+    cmds = child_commands(args, argv)
+    if args.dry_run:
+        print(json.dumps([{"argv": c, "env": e} for c, e in cmds]))
+        return 0
+    procs = []
+    for r, (cmd, env) in enumerate(cmds):
+        e = dict(os.environ)
+        e.update(env)
+        # rank 0 owns stdout (the JSON line); the other ranks' stdout goes to stderr
+        procs.append(subprocess.Popen(cmd, env=e, stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+# --------------------------------------------------------------------------------------------
 def algorithmic_bytes(width, height, levels, detect_levels, cells, k_out):
     """B_frame = P0 + 2 * sum(P_l) + 52 * K_out, and its per-kernel split."""
     p = [(width >> l) * (height >> l) for l in range(levels)]
@@ -54,14 +119,27 @@ def algorithmic_bytes(width, height, levels, detect_levels, cells, k_out):
     return dict(frame=frame, pyramid=pyramid, detect=detect, describe=describe)
 
 
-def cpu_baseline(frames, mode, seconds=12.0):
-    """Oracle (CPU port of the reference semantics) timed on this host: extract + match."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(frames, mode, seconds_1t=7.0, seconds_mt=10.0):
+    """Oracle (CPU port of the reference semantics) timed on this host: extract + match, first on
+    one thread, then frame-parallel on the box's CPU share."""
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
     from concurrent.futures import ThreadPoolExecutor
     m = MODES[mode]
     ocfg = oracle.make_config(m["width"], m["height"], **m["cfg"])
     cores = max(1, min(len(os.sched_getaffinity(0)), 16))  # a 1-GPU box has a 16-CPU share
+    mm = m["match"]
 
     def comp(d):
         return ((d == 1).astype(np.uint32) << np.arange(32, dtype=np.uint32)).sum(1).astype(np.uint32)
@@ -72,29 +150,62 @@ def cpu_baseline(frames, mode, seconds=12.0):
     def match(pair):
         a, b = pair
         pa, pb = np.stack([a["x"], a["y"]], 1), np.stack([b["x"], b["y"]], 1)
-        if m["match"]["mode"] == 1:
-            oracle.match256(a["desc"], b["desc"], pa, pb, m["match"]["window"], m["match"]["max_distance"])
+        if mm["mode"] == 1:
+            oracle.match256(a["desc"], b["desc"], pa, pb, mm["window"], mm["max_distance"])
         else:
-            oracle.match_keypoints(pa, comp(a["desc"]), pb, comp(b["desc"]), m["match"]["window"],
-                                   m["match"]["max_distance"])
+            oracle.match_keypoints(pa, comp(a["desc"]), pb, comp(b["desc"]), mm["window"], mm["max_distance"])
 
-    # time-bounded: chunks of `cores` frames (extract, then match consecutive pairs) until the
-    # budget is spent, so the sample stays ~`seconds` whatever the host's real CPU share is
-    recs_prev, n_frames, n_pairs, kp = None, 0, 0, 0
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:  # ctypes releases the GIL inside the oracle
-        while time.perf_counter() - t0 < seconds:
-            recs = list(ex.map(extract, range(n_frames, n_frames + cores)))
-            chain = ([recs_prev] if recs_prev is not None else []) + recs
-            list(ex.map(match, zip(chain[:-1], chain[1:])))
-            n_pairs += len(chain) - 1
-            n_frames += len(recs)
-            kp += sum(len(r) for r in recs)
-            recs_prev = recs[-1]
-    dt = time.perf_counter() - t0
-    return dict(value=kp / dt, unit="keypoints/s", cores=cores, kind="port",
-                sample="%d frames extracted + %d frame pairs matched by the CPU oracle on %d threads "
-                       "in %.1f s" % (n_frames, n_pairs, cores, dt))
+    stride = m["stride"]
+
+    def run(threads, seconds):
+        # time-bounded: chunks of `threads` frames (extract, then match the mode's pairs) until the
+        # budget is spent, so the sample stays ~`seconds` whatever the host's real CPU share is
+        chunk = threads + (threads % 2 if stride == 2 else 0)
+        recs_prev, n_frames, n_pairs, kp = None, 0, 0, 0
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(threads) as ex:  # ctypes releases the GIL inside the oracle
+            while time.perf_counter() - t0 < seconds:
+                recs = list(ex.map(extract, range(n_frames, n_frames + chunk)))
+                if mm is not None:
+                    if stride == 2:  # stereo: (left, right) pairs only
+                        prs = list(zip(recs[0::2], recs[1::2]))
+                    else:            # temporal: t-1 -> t, chained across chunks
+                        chain = ([recs_prev] if recs_prev is not None else []) + recs
+                        prs = list(zip(chain[:-1], chain[1:]))
+                    list(ex.map(match, prs))
+                    n_pairs += len(prs)
+                n_frames += len(recs)
+                kp += sum(len(r) for r in recs)
+                recs_prev = recs[-1]
+        dt = time.perf_counter() - t0
+        return kp / dt, n_frames / dt, n_frames, n_pairs, dt
+
+    v1, f1, n1, p1, t1 = run(1, seconds_1t)
+    vm, fm, nm, pm, tm = run(cores, seconds_mt)
+    return dict(value=vm, unit="keypoints/s", cores=cores, kind="port", frames_per_s=fm,
+                single_thread=dict(value=v1, unit="keypoints/s", cores=1, frames_per_s=f1,
+                                   sample="%d frames + %d pairs in %.1f s" % (n1, p1, t1)),
+                cpu_model=cpu_model(),
+                sample="%d frames extracted + %d frame pairs matched by the CPU oracle on %d threads in %.1f s "
+                       "(and %d frames + %d pairs on 1 thread in %.1f s)" % (nm, pm, cores, tm, n1, p1, t1))
+
+
+def make_scenes(synth, mode, scene, n_distinct, first_index):
+    """Synthetic frames [n, H, W] u8.  `dense`: corner-rich scenes that fill the feature budget
+    (rectangles of 6..32 px, 800 per 640x480 of area); `survey`: SURVEY.md 8d's generator (96
+    rectangles up to a fifth of the frame, +-3 noise)."""
+    import numpy as np
+    m = MODES[mode]
+    w, h = m["width"], m["height"]
+    kw = dict(n_rects=96) if scene == "survey" else \
+        dict(n_rects=800 * (w * h) // (640 * 480), min_size=6, max_size=32)
+    if mode == "c3":  # (left, right) pairs: the same scene shifted by 3 px with fresh +-2 noise
+        out = []
+        for i in range(n_distinct // 2):
+            a, b = synth.shifted_pair(w, h, first_index + i, dx=3, dy=0, **kw)
+            out += [a, b]
+        return np.stack(out)
+    return synth.frames(w, h, n_distinct, first_index=first_index, kind="rects", **kw)
 
 
 def main():
@@ -102,39 +213,57 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--mode", choices=sorted(MODES), default="c2")
+    ap.add_argument("--batch", type=int, default=0, help="frames per GPU per step (c2/ref/c3), total frames (c4); "
+                                                           "0 = the mode's default")
+    ap.add_argument("--scene", choices=("dense", "survey"), default="dense")
+    ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic frames per rank (repeated to fill the batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (survey scene, no-gather rate)")
     ap.add_argument("--rgb", action="store_true",
                     help="feed interleaved RGB8 frames (SURVEY.md 8f-1): the gray conversion is fused into "
                          "the pyramid kernel; not the BASELINE metric (its configs are grayscale)")
-    ap.add_argument("--gather", action="store_true",
-                    help="N > 1: also gather every rank's keypoint records to rank 0 each step (asynchronous, "
-                         "double-buffered).  Off by default: the frames are independent and the path has no "
-                         "exchange step (26.6 MB per rank and step would ride on one xGMI link each)")
-    ap.add_argument("--stage-iters", type=int, default=10, help="(unused; kept for old command lines)")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the keypoint gather out of the timed region")
+    ap.add_argument("--exact-gather", action="store_true", help="N > 1: variable-length gather (counts first, then exactly "
+                                                                  "sum(counts) * 52 bytes per rank)")
+    ap.add_argument("--dry-run", action="store_true", help="with --gpus N: print the child command lines and exit")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # this process has not imported torch or touched HIP: start the ranks as children
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
+    if args.dry_run:
+        print(json.dumps([]))
+        return
+
+    import numpy as np
     import torch
     import torch.distributed as dist
     import orbfe
-    if not os.path.exists(orbfe.LIB_PATH) and int(os.environ.get("LOCAL_RANK", "0")) == 0:
-        import __graft_entry__  # clean checkout: compile the HIP library first (hipcc, gfx950)
-        __graft_entry__.build()
-    from orbfe import synth
-    from orbfe.dist import gather_keypoints_async
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE is %d (launch with --nproc-per-node %d or drop WORLD_SIZE)"
+                 % (args.gpus, world, args.gpus))
+    if not os.path.exists(orbfe.LIB_PATH) and local_rank == 0:
+        import __graft_entry__  # clean checkout: compile the HIP library first (hipcc, gfx950)
+        __graft_entry__.build()
+    from orbfe import synth
+    from orbfe.dist import RcclComm, gather_keypoints_async, merge_cell_keys, shard_range
+
+    share = os.environ.get("ORBFE_BENCH_SHARE_GPU") == "1"  # rehearsal on a 1-GPU box: every rank on cuda:0, gloo
+    comm = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # ORBFE_BENCH_SHARE_GPU=1 (rehearsal on a 1-GPU box only): every rank uses cuda:0 and the
-        # collectives go over gloo, because RCCL refuses two ranks on one device
-        share = os.environ.get("ORBFE_BENCH_SHARE_GPU") == "1"
         if share:
             local_rank = 0
+        elif torch.cuda.device_count() < world:
+            sys.exit("bench.py: %d ranks but %d HIP devices (ORBFE_BENCH_SHARE_GPU=1 rehearses on one)"
+                     % (world, torch.cuda.device_count()))
         torch.cuda.set_device(local_rank)
         if share:
             dist.init_process_group("gloo")
@@ -143,182 +272,290 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    if world > 1 and not share:
+        def exchange(ident):  # rank 0's RCCL unique id reaches the other ranks through torch.distributed
+            t = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                t.copy_(torch.frombuffer(bytearray(ident), dtype=torch.uint8))
+            dist.broadcast(t, 0)
+            return bytes(t.cpu().numpy().tobytes())
+        comm = RcclComm(rank, world, local_rank, exchange)
 
     m = MODES[args.mode]
-    w, h, B = m["width"], m["height"], args.batch
-    ctx = orbfe.Context(w, h, max_batch=B, device=local_rank, **m["cfg"])
-    # synthetic data: 16 distinct corner-rich scenes per rank, repeated to fill the batch
-    n_distinct = min(16, B)
-    base = synth.frames(w, h, n_distinct, first_index=1000 * rank, kind="rects", **synth.DENSE)
-    frames = torch.from_numpy(base).to(dev)[torch.arange(B, device=dev) % n_distinct].contiguous()
-    if args.rgb:  # R = G = B = gray scene +- a channel-dependent offset: corners survive the conversion
-        off = torch.tensor([3, 0, -3], dtype=torch.int16, device=dev)
-        frames = (frames.to(torch.int16).unsqueeze(-1) + off).clamp(0, 255).to(torch.uint8).contiguous()
-    # records / counts are double-buffered: the gather of step i (RCCL, asynchronous) overlaps
-    # the kernels of step i + 1, which write the other buffer
-    recs = [torch.zeros(B * ctx.cap * 52, dtype=torch.uint8, device=dev) for _ in range(2)]
-    cnts = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
-    rec, cnt = recs[0], cnts[0]
-    idx = torch.zeros(max(B - 1, 1) * ctx.cap, dtype=torch.int32, device=dev)
-    dst = torch.zeros(max(B - 1, 1) * ctx.cap, dtype=torch.int32, device=dev)
-    s = torch.cuda.current_stream().cuda_stream
+    w, h = m["width"], m["height"]
+    total = args.batch or m["batch"]
+    if m["scaling"] == "strong":
+        f0, f1 = shard_range(total, rank, world) if args.mode != "c5" else (0, 1)
+        B = f1 - f0
+    else:
+        f0, B = 0, total
+    if args.mode == "c3" and B % 2:
+        sys.exit("bench.py: c3 needs an even number of frames (stereo pairs)")
     mm = m["match"]
+    s = torch.cuda.current_stream().cuda_stream
+
+    def build_input(scene):
+        n_distinct = max(min(args.distinct, B), 1)
+        if args.mode == "c3":
+            n_distinct += n_distinct % 2
+        # every rank sees different scenes; strong-scaling modes index them by global frame number
+        first = (f0 if m["scaling"] == "strong" else 1000 * rank)
+        base = make_scenes(synth, args.mode, scene, n_distinct, first)
+        fr = torch.from_numpy(base).to(dev)[torch.arange(B, device=dev) % len(base)].contiguous()
+        if args.rgb:  # R = G = B = gray scene +- a channel-dependent offset: corners survive the conversion
+            off = torch.tensor([3, 0, -3], dtype=torch.int16, device=dev)
+            fr = (fr.to(torch.int16).unsqueeze(-1) + off).clamp(0, 255).to(torch.uint8).contiguous()
+        return base, fr
+
+    ctx = orbfe.Context(w, h, max_batch=max(B, 1), device=local_rank, **m["cfg"]) if B > 0 else None
+    cap = ctx.cap if ctx else 0
+    n_pairs = max((B - 2) // m["stride"] + 1, 0) if (mm and B >= 2) else 0
+    # records / counts are double-buffered: the gather of step i overlaps the kernels of step i + 1
+    recs = [torch.zeros(max(B, 1) * max(cap, 1) * 52, dtype=torch.uint8, device=dev) for _ in range(2)]
+    cnts = [torch.zeros(max(B, 1), dtype=torch.int32, device=dev) for _ in range(2)]
+    idx = torch.zeros(max(n_pairs, 1) * max(cap, 1), dtype=torch.int32, device=dev)
+    dst = torch.zeros(max(n_pairs, 1) * max(cap, 1), dtype=torch.int32, device=dev)
+    keys = torch.zeros(max(ctx.K if ctx else 1, 1), dtype=torch.int32, device=dev) if args.mode == "c5" else None
+    equal_shards = m["scaling"] == "weak" or total % world == 0
+    gather_ok = world > 1 and args.mode != "c5" and equal_shards
     gather_out = None
-    do_gather = world > 1 and args.gather
-    if do_gather and rank == 0:
-        gather_out = [(torch.empty((world, B * ctx.cap * 52), dtype=torch.uint8, device=dev),
+    if gather_ok and rank == 0:
+        gather_out = [(torch.empty((world, B * cap * 52), dtype=torch.uint8, device=dev),
                        torch.empty((world, B), dtype=torch.int32, device=dev)) for _ in range(2)]
-    pending = [None, None]
-    step_no = [0]
+    state = dict(frames=None, step=0, tickets=[0, 0], pending=[None, None], events=[])
 
-    stage_events = []  # per timed step: 5 events bracketing pyramid | detect | describe | match
-
-    def step(record=False):
-        b = step_no[0] & 1
-        step_no[0] += 1
-        if pending[b] is not None:  # the gather that last read this buffer must be done
-            pending[b].wait()
-            pending[b] = None
+    def run_step(record, do_gather):
+        b = state["step"] & 1
+        state["step"] += 1
+        frames = state["frames"]
+        if do_gather:  # the gather that last read this buffer pair must be done before it is rewritten
+            if comm is not None:
+                comm.wait_ticket(state["tickets"][b], s)
+            elif state["pending"][b] is not None:
+                state["pending"][b].wait()
+                state["pending"][b] = None
         r, c = recs[b], cnts[b]
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if record else None
         # orbfe_extract == build_pyramid + detect_batch + describe_batch; issued separately so
         # that HIP events on this stream can time each stage inside the timed region
         if ev: ev[0].record()
-        if args.rgb:
-            orbfe.check(orbfe.lib().orbfe_build_pyramid_rgb(ctx.handle, frames.data_ptr(), 3 * w, 3 * w * h, B, s),
-                        ctx.handle)
-        else:
-            ctx.build_pyramid(frames.data_ptr(), w, w * h, B, s)
+        if B > 0:
+            if args.rgb:
+                orbfe.check(orbfe.lib().orbfe_build_pyramid_rgb(ctx.handle, frames.data_ptr(), 3 * w, 3 * w * h, B, s),
+                            ctx.handle)
+            else:
+                ctx.build_pyramid(frames.data_ptr(), w, w * h, B, s)
         if ev: ev[1].record()
-        ctx.detect_batch(B, s)
+        if args.mode == "c5":
+            ctx.detect_batch_shard(B, rank, world, s)
+            if world > 1:  # partial per-cell keys -> element-wise MAX over the ranks -> back into the context
+                ctx.export_cell_keys(B, keys.data_ptr(), s)
+                if comm is not None:
+                    comm.allreduce_max_keys(keys.data_ptr(), ctx.K, s)
+                    comm.wait(s)
+                else:
+                    merge_cell_keys(keys)
+                ctx.import_cell_keys(B, keys.data_ptr(), s)
+        elif B > 0:
+            ctx.detect_batch(B, s)
         if ev: ev[2].record()
-        ctx.describe_batch(B, r.data_ptr(), c.data_ptr(), None, s)
+        if B > 0:
+            ctx.describe_batch(B, r.data_ptr(), c.data_ptr(), None, s)
         if ev: ev[3].record()
-        ctx.match_batch(r.data_ptr(), c.data_ptr(), B, mm["mode"], mm["window"], mm["max_distance"],
-                        idx.data_ptr(), dst.data_ptr(), s)
+        if n_pairs > 0:
+            ctx.match_pairs(r.data_ptr(), c.data_ptr(), B, 0, m["stride"], mm["mode"], mm["window"], mm["max_distance"],
+                            idx.data_ptr(), dst.data_ptr(), s)
         if ev:
             ev[4].record()
-            stage_events.append(ev)
+            state["events"].append(ev)
         if do_gather:
-            pending[b] = gather_keypoints_async(r, c, gather_out[b] if gather_out else None, dst=0)
-
-    def drain():
-        for b in (0, 1):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
+            if comm is not None:
+                go = gather_out[b] if gather_out else (None, None)
+                comm.gather_keypoints(r.data_ptr(), c.data_ptr(), B, cap, go[0].data_ptr() if go[0] is not None else None,
+                                      go[1].data_ptr() if go[1] is not None else None, 0, args.exact_gather, s)
+                state["tickets"][b] = comm.ticket()
+            else:
+                state["pending"][b] = gather_keypoints_async(r, c, gather_out[b] if gather_out else None, dst=0)
 
     def sync():
-        drain()
+        for b in (0, 1):
+            if state["pending"][b] is not None:
+                state["pending"][b].wait()
+                state["pending"][b] = None
+        if comm is not None:
+            comm.sync()  # "gather complete on rank 0"
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(record=True)
-    sync()
-    elapsed = time.perf_counter() - t0
-    counts = cnt.cpu().numpy().astype(np.int64)
-    kp_local = int(counts.sum())
-    pairs_local = int((counts[:-1] * counts[1:]).sum())
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tot = torch.tensor([kp_local, pairs_local], dtype=torch.int64, device=dev)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        kp_total, pairs_total = int(tot[0].item()), int(tot[1].item())
-    else:
-        kp_total, pairs_total = kp_local, pairs_local
+    def timed(frames, do_gather, record):
+        state["frames"] = frames
+        state["events"] = []
+        for _ in range(args.warmup):
+            run_step(False, do_gather)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run_step(record, do_gather)
+        sync()
+        elapsed = time.perf_counter() - t0
+        counts = cnts[(state["step"] - 1) & 1].cpu().numpy().astype(np.int64)[:B]
+        kp_local = int(counts.sum())
+        prs = [int(counts[k * m["stride"]] * counts[k * m["stride"] + 1]) for k in range(n_pairs)]
+        pairs_local = int(sum(prs))
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev if not share else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            tot = torch.tensor([kp_local, pairs_local, B], dtype=torch.int64, device=dev if not share else "cpu")
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            kp_total, pairs_total, frames_total = (int(v) for v in tot.tolist())
+        else:
+            kp_total, pairs_total, frames_total = kp_local, pairs_local, B
+        if args.mode == "c5":  # every rank describes the same merged frame: count it once
+            kp_total, frames_total = kp_local, 1
+        return dict(elapsed=elapsed, counts=counts, kp_local=kp_local, pairs_local=pairs_local, kp_total=kp_total,
+                    pairs_total=pairs_total, frames_total=frames_total, events=state["events"])
 
-    # ---- per-stage device time: HIP events recorded on the kernels' stream inside the timed
-    #      region (averaged over the K timed steps)
+    use_gather = gather_ok and not args.no_gather
+    base, frames = build_input(args.scene)
+    main_run = timed(frames, use_gather, True)
+    extras = {}
+    if not args.no_extras:
+        if use_gather:  # the same steps without the collective
+            r2 = timed(frames, False, False)
+            extras["no_gather"] = {"value": r2["kp_total"] * args.steps / r2["elapsed"], "unit": "keypoints/s",
+                                   "ms_per_step": r2["elapsed"] / args.steps * 1e3}
+        other = "survey" if args.scene == "dense" else "dense"
+        _, frames2 = build_input(other)
+        r3 = timed(frames2, use_gather, False)
+        extras[other + "_scene"] = {"value": r3["kp_total"] * args.steps / r3["elapsed"], "unit": "keypoints/s",
+                                    "ms_per_step": r3["elapsed"] / args.steps * 1e3,
+                                    "frames_per_s": r3["frames_total"] * args.steps / r3["elapsed"],
+                                    "keypoints_per_frame": r3["kp_total"] / max(r3["frames_total"], 1)}
+        del frames2
+
     out = None
     if rank == 0:
+        R = main_run
         names = ("pyramid", "detect", "describe", "match")
         ms = {k: 0.0 for k in names}
-        for ev in stage_events:
+        for ev in R["events"]:
             for i, k in enumerate(names):
                 ms[k] += ev[i].elapsed_time(ev[i + 1])
-        ms_pyr, ms_det, ms_desc, ms_match = (ms[k] / max(len(stage_events), 1) for k in names)
-        detect_levels = sum(1 for l in range(m["cfg"]["levels"]) if (m["cfg"]["cell"] >> l) > 0
-                            and (w >> l) > 0 and (h >> l) > 0)
-        k_out = kp_local / B
-        ab = algorithmic_bytes(w, h, m["cfg"]["levels"], detect_levels, ctx.K, k_out)
-        stages = {"pyramid": ms_pyr, "detect": ms_det, "describe": ms_desc, "match": ms_match}
-        # matcher bytes, SURVEY.md 8d: 40 B per descriptor+position in, 8 B (idx, dist) out
-        c64 = counts.astype(np.int64)
-        ab["match"] = float((40 * (c64[:-1] + c64[1:]) + 8 * c64[:-1]).sum()) / B if mm["mode"] == 1 else \
-            float((12 * (c64[:-1] + c64[1:]) + 8 * c64[:-1]).sum()) / B
+        stages = {k: ms[k] / max(len(R["events"]), 1) for k in names}
+        cfg = m["cfg"]
+        detect_levels = sum(1 for l in range(cfg["levels"]) if (cfg["cell"] >> l) > 0 and (w >> l) > 0 and (h >> l) > 0)
+        k_out = R["kp_local"] / max(B, 1)
+        ab = algorithmic_bytes(w, h, cfg["levels"], detect_levels, ctx.K, k_out)
+        c64 = R["counts"]
+        st = m["stride"]
+        if n_pairs:
+            a_, b_ = c64[0:n_pairs * st:st], c64[1:n_pairs * st + 1:st]
+            per = (40 if mm["mode"] == 1 else 12)
+            ab["match"] = float((per * (a_ + b_) + 8 * a_).sum()) / B  # descriptor + position in, (idx, dist) out
+        else:
+            ab["match"] = 0.0
+        mfma_match = bool(mm) and mm["mode"] == 1 and mm["window"] < 0
         kernels = {"pyramid": "pyramid_fused_kernel", "detect": "detect_tile_kernel",
                    "describe": "select_kernel+describe_kernel",
-                   "match": "match_expand_kernel+match_mfma_kernel" if mm["mode"] == 1 else "match_batch_ref_kernel"}
-        traffic_all = {}
+                   "match": ("match_expand_kernel+match_mfma_kernel" if mfma_match else
+                             "match_gather_kernel+match_batch_256_kernel" if (mm and mm["mode"] == 1) else
+                             "match_batch_ref_kernel")}
+        prof = {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and B == 256:  # the PMC passes were taken at batch 256
             try:
-                traffic_all = json.load(open(tpath)).get(args.mode, {})
+                prof = json.load(open(tpath)).get(args.mode, {})
             except Exception:
-                traffic_all = {}
-        per_stage = {k: {"kernel": kernels[k], "ms": stages[k], "algorithmic_bytes": ab[k] * B,
-                         "achieved_GBps": ab[k] * B / (stages[k] * 1e-3) / 1e9,
-                         "frac": ab[k] * B / (stages[k] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                         "traffic": traffic_all.get(k)} for k in stages}
-        if mm["mode"] == 1:
+                prof = {}
+        valu_counts = prof.get("valu_wave_instructions", {})
+        per_stage = {}
+        for k in names:
+            t = stages[k] * 1e-3
+            if t <= 0:
+                continue
+            e = {"kernel": kernels[k], "ms": stages[k], "algorithmic_bytes": ab[k] * B,
+                 "achieved_GBps": ab[k] * B / t / 1e9, "frac": ab[k] * B / t / 1e9 / HBM_PEAK_GBPS,
+                 "traffic": prof.get(k)}
+            if valu_counts.get(k):  # VALU wave-instructions per launch (rocprofv3 SQ_INSTS_VALU) x 64 lanes
+                ach = valu_counts[k] * 64 / t / 1e12
+                e["valu"] = {"bound": "valu", "unit": "Tlane-op/s", "achieved": ach, "peak": VALU_PEAK_TLANEOPS,
+                             "frac": ach / VALU_PEAK_TLANEOPS, "wave_instructions_per_launch": valu_counts[k]}
+            per_stage[k] = e
+        if mfma_match and "match" in per_stage:
             # the 256-bit matcher runs on the matrix cores: 2 x 256 flop per pair on e2m1 operands,
             # dense FP4 MFMA peak ~10 PFLOP/s (MI355X_MICROARCH.md, Matrix cores)
-            flops = 512.0 * pairs_local
+            flops = 512.0 * R["pairs_local"]
+            t = stages["match"] * 1e-3
             per_stage["match"]["mfma"] = {"bound": "mfma", "unit": "TFLOP/s", "peak": FP4_MFMA_PEAK_TFLOPS,
-                                          "achieved": flops / (ms_match * 1e-3) / 1e12,
-                                          "frac": flops / (ms_match * 1e-3) / 1e12 / FP4_MFMA_PEAK_TFLOPS,
+                                          "achieved": flops / t / 1e12, "frac": flops / t / 1e12 / FP4_MFMA_PEAK_TFLOPS,
                                           "flops_per_launch": flops}
-        dom = max(stages, key=lambda k: stages[k])  # the kernel with the largest share of the step
-        dom_kernel = kernels[dom]
-        achieved = per_stage[dom]["achieved_GBps"]
-        traffic = traffic_all.get(dom)
-        ms_extract = ms_pyr + ms_det + ms_desc
+        dom = max(per_stage, key=lambda k: stages[k])  # the kernel with the largest share of the step
+        ms_extract = stages["pyramid"] + stages["detect"] + stages["describe"]
+        hbm = {"bound": "hbm", "achieved": per_stage[dom]["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+               "frac": per_stage[dom]["frac"], "traffic": per_stage[dom]["traffic"]}
+        # what bounds the dominant kernel: the PMC passes (profiles/) show detect and describe at 75-90 %
+        # VALU busy and a few % of the HBM roofline, the pyramid kernel at 63 % of it
+        limiter = "valu" if dom in ("detect", "describe") else ("mfma" if dom == "match" and mfma_match else "hbm")
+        roof = dict(hbm)
+        if limiter == "valu" and "valu" in per_stage[dom]:
+            roof = dict(per_stage[dom]["valu"])
+            roof["traffic"] = per_stage[dom]["traffic"]
+        elif limiter == "mfma":
+            roof = dict(per_stage[dom]["mfma"])
+            roof["traffic"] = per_stage[dom]["traffic"]
+        roof.update({"kernel": kernels[dom], "limiter": limiter, "hbm": hbm,
+                     "algorithmic_bytes_per_launch": ab[dom] * B, "avg_launch_ms": stages[dom],
+                     "note": "declared roofline of the tier is HBM (`hbm`: algorithmic bytes / launch time / 8 TB/s); "
+                             "`bound` is what the counters show limits the dominant kernel (DESIGN.md section 4)",
+                     "stages": per_stage})
+        elapsed = R["elapsed"]
         out = {
-            "metric": "ORB keypoints/sec end-to-end (extract + match), 640x480 8-level",
-            "value": kp_total * args.steps / elapsed,
+            "metric": "ORB keypoints/sec end-to-end (extract + match), %dx%d %d-level" % (w, h, cfg["levels"]),
+            "value": R["kp_total"] * args.steps / elapsed,
             "unit": "keypoints/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": m["scaling"], "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": m["workload"] + (" [RGB8 input, conversion fused]" if args.rgb else ""),
-                       "frames_per_gpu_per_step": B,
-                       "frames_per_step": B * world, "keypoints_per_frame": k_out,
-                       "collective": ("async gather of 52-byte keypoint records to rank 0, overlapped with the "
-                                      "next step" if do_gather else
-                                      "none in the data path (independent frames); barrier + timing reductions only")},
-            "frames_per_s": B * world * args.steps / elapsed,
-            "matcher_gpairs_per_s": pairs_local / (ms_match * 1e-3) / 1e9,
-            "matcher_pairs_per_step": pairs_total,
+                       "mode": args.mode,
+                       "scene": ("dense: 800 rectangles of 6..32 px per 640x480 of area + noise (fills the feature budget)"
+                                 if args.scene == "dense" else
+                                 "survey: SURVEY.md 8d generator, 96 rectangles up to a fifth of the frame + -3..3 noise"),
+                       "distinct_frames_per_rank": int(len(base)),
+                       "frames_per_gpu_per_step": B, "frames_per_step": R["frames_total"],
+                       "keypoints_per_frame": R["kp_total"] / max(R["frames_total"], 1),
+                       "collective": (("RCCL (liborbfe_dist.so: grouped ncclSend/ncclRecv, %s) gather of 52-byte keypoint "
+                                       "records + counts to rank 0 inside the timed region, overlapped with the next step"
+                                       % ("exact length" if args.exact_gather else "fixed stride")) if use_gather and comm
+                                      else "torch.distributed gloo gather (shared-GPU rehearsal)" if use_gather
+                                      else "RCCL all-reduce(MAX) of the per-cell keys (liborbfe_dist.so)" if (args.mode == "c5" and world > 1)
+                                      else "none in the data path; barrier + timing reductions only")},
+            "frames_per_s": R["frames_total"] * args.steps / elapsed,
+            "matcher_gpairs_per_s": (R["pairs_local"] / (stages["match"] * 1e-3) / 1e9) if stages["match"] > 0 else None,
+            "matcher_pairs_per_step": R["pairs_total"],
             "stage_ms": stages,
             "path_hbm": {"algorithmic_bytes_per_frame": ab["frame"],
                          "achieved_GBps": ab["frame"] * B / (ms_extract * 1e-3) / 1e9,
                          "frac_of_8TBps": ab["frame"] * B / (ms_extract * 1e-3) / 1e9 / HBM_PEAK_GBPS},
-            "roofline": {"bound": "hbm", "kernel": dom_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": ab[dom] * B, "avg_launch_ms": stages[dom],
-                         "note": "declared roofline is HBM; the kernels are VALU-issue bound on MI355X "
-                                 "(DESIGN.md section 4), so frac stays small by construction",
-                         "stages": per_stage},
+            "roofline": roof,
         }
+        out.update(extras)
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(base, args.mode)
-        elif world > 1:
+        else:
             out["cpu_baseline"] = None
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":

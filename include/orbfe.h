@@ -14,9 +14,11 @@
  *     (checkCudaErrors / exit(1), src/cuda_common.h:69-77); orbfe_last_error() gives text.
  *   - no global mutable state: the rBRIEF pattern is a compile-time constant (the
  *     reference uploads it with loadPattern(), src/cuda/orb.cu:218-225) and the FAST LUT
- *     is a caller buffer as in the reference.  A context is thread-compatible: one
- *     context per host thread + stream, as the reference runs one buildStream thread per
- *     stream (src/SlamGpuPipeline/SlamGpuPipeline.cpp:43-50).
+ *     is a caller buffer as in the reference.  A context is thread-compatible, not
+ *     thread-safe: ONE context = ONE host thread + ONE stream at a time (its pyramid, cell
+ *     keys and matcher scratch are single copies), as the reference runs one buildStream
+ *     thread per stream (src/SlamGpuPipeline/SlamGpuPipeline.cpp:43-50).  Calls leave the
+ *     caller's current HIP device unchanged.
  *   - there is NO CPU fallback: without a HIP device every call returns ORBFE_ERR_NO_DEVICE
  *     or ORBFE_ERR_HIP.
  */
@@ -272,6 +274,14 @@ int orbfe_extract_rgb(orbfe_ctx *ctx, const uint8_t *d_rgb, size_t pitch, size_t
 int orbfe_match_batch(orbfe_ctx *ctx, const orbfe_keypoint *d_records, const int32_t *d_counts,
                       int n_frames, int mode, int window, int max_distance, int32_t *d_idx,
                       int32_t *d_dist, orbfe_stream_t stream);
+
+/* The same for an arbitrary pair list inside the batch: pair k = (prev frame first + k * stride,
+ * curr frame first + k * stride + 1) for every k whose curr frame is < n_frames; results of
+ * pair k at d_idx / d_dist + k * max_keypoints.  orbfe_match_batch == first 0, stride 1;
+ * stereo pairs (left, right, left, right ...) == first 0, stride 2 (config C3). */
+int orbfe_match_pairs(orbfe_ctx *ctx, const orbfe_keypoint *d_records, const int32_t *d_counts,
+                      int n_frames, int first, int stride, int mode, int window, int max_distance,
+                      int32_t *d_idx, int32_t *d_dist, orbfe_stream_t stream);
 
 /* ================= harness helpers (tests, bench) ===================================== */
 int orbfe_device_count(void);

@@ -937,13 +937,13 @@ __device__ inline uint32_t compress_words(const uint32_t w[8])
 
 __global__ void __launch_bounds__(256)
 match_batch_ref_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *__restrict__ counts,
-                       int cap, float win, int max_ham, int32_t *__restrict__ out_idx,
+                       int cap, int first, int stride, float win, int max_ham, int32_t *__restrict__ out_idx,
                        int32_t *__restrict__ out_dist)
 {
     __shared__ float s_x[32], s_y[32];
     __shared__ uint32_t s_d[32];
-    const int p = blockIdx.y;
-    const int nA = counts[p], nB = counts[p + 1];
+    const int pk = blockIdx.y, p = first + pk * stride; // pair ordinal, prev frame
+    const int nA = clamp_count(counts[p], cap), nB = clamp_count(counts[p + 1], cap);
     const uint32_t *A = reinterpret_cast<const uint32_t *>(records + (size_t)p * cap);
     const uint32_t *B = reinterpret_cast<const uint32_t *>(records + (size_t)(p + 1) * cap);
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -989,8 +989,8 @@ match_batch_ref_kernel(const orbfe_keypoint *__restrict__ records, const int32_t
         }
     }
     if (i < cap) {
-        out_idx[(size_t)p * cap + i] = live ? pair : -1;
-        if (out_dist) out_dist[(size_t)p * cap + i] = (live && pair >= 0) ? best : -1;
+        out_idx[(size_t)pk * cap + i] = live ? pair : -1;
+        if (out_dist) out_dist[(size_t)pk * cap + i] = (live && pair >= 0) ? best : -1;
     }
 }
 
@@ -1017,7 +1017,7 @@ match_gather_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *_
     const size_t o = (size_t)f * cap + i;
     Desc8 d = {{0, 0, 0, 0, 0, 0, 0, 0}};
     float2 p = make_float2(0.f, 0.f);
-    if (i < counts[f]) {
+    if (i < clamp_count(counts[f], cap)) {
         const uint32_t *r = reinterpret_cast<const uint32_t *>(records + o);
         p = make_float2(__uint_as_float(r[0]), __uint_as_float(r[1]));
 #pragma unroll
@@ -1030,12 +1030,13 @@ match_gather_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *_
 template <bool WINDOW>
 __global__ void __launch_bounds__(256)
 match_batch_256_kernel(const Desc8 *__restrict__ mdesc, const float2 *__restrict__ mpos,
-                       const int32_t *__restrict__ counts, int cap, int window, int max_dist,
+                       const int32_t *__restrict__ counts, int cap, int first, int stride, int window, int max_dist,
                        int32_t *__restrict__ out_idx, int32_t *__restrict__ out_dist)
 {
-    int p, blk;
-    xcd_remap(gridDim.x, gridDim.y, &p, &blk); // all query blocks of a pair share one L2
-    const int nA = counts[p], nB = counts[p + 1];
+    int pk, blk;
+    xcd_remap(gridDim.x, gridDim.y, &pk, &blk); // all query blocks of a pair share one L2
+    const int p = first + pk * stride;
+    const int nA = clamp_count(counts[p], cap), nB = clamp_count(counts[p + 1], cap);
     const int i = blk * 256 + threadIdx.x;
     const Desc8 *__restrict__ Bd = mdesc + (size_t)(p + 1) * cap;
     const float2 *__restrict__ Bp = mpos + (size_t)(p + 1) * cap;
@@ -1123,8 +1124,8 @@ match_batch_256_kernel(const Desc8 *__restrict__ mdesc, const float2 *__restrict
     if (i < cap) {
         const int bd = (int)(best >> 16), bj = (int)(best & 0xFFFFu);
         const bool ok = live && best != 0xFFFFFFFFu && bd <= max_dist;
-        out_idx[(size_t)p * cap + i] = ok ? bj : -1;
-        if (out_dist) out_dist[(size_t)p * cap + i] = ok ? bd : -1;
+        out_idx[(size_t)pk * cap + i] = ok ? bj : -1;
+        if (out_dist) out_dist[(size_t)pk * cap + i] = ok ? bd : -1;
     }
 }
 
@@ -1137,6 +1138,21 @@ using namespace orbfe;
 
 static inline hipStream_t S(orbfe_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Identity of the graph capture `stream` is in (0 = not capturing).  The "cell keys are already
+// clear" shortcut between build_pyramid and detect_batch is a host-side flag, so it is only valid
+// when both calls are issued on the same stream in the same mode: both eager, or both inside the
+// same capture (then the graph contains the clearing kernel too).
+static unsigned long long capture_id_of(hipStream_t stream)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    if (hipStreamGetCaptureInfo(stream, &st, &id) != hipSuccess) {
+        (void)hipGetLastError();
+        return ~0ull; // unknown: never matches
+    }
+    return st == hipStreamCaptureStatusActive ? (id ? id : ~0ull - 1) : 0ull;
+}
 
 #define CTX_FAIL(ctx, code, ...)                                                            \
     do {                                                                                    \
@@ -1192,7 +1208,8 @@ int orbfe_create(const orbfe_config *cfg, orbfe_ctx **out)
         CTX_FAIL((orbfe_ctx *)nullptr, ORBFE_ERR_NO_DEVICE, "orbfe_create: no HIP device (this library has no CPU fallback)");
     if (cfg->device < 0 || cfg->device >= ndev)
         CTX_FAIL((orbfe_ctx *)nullptr, ORBFE_ERR_INVALID_ARG, "orbfe_create: device %d of %d", cfg->device, ndev);
-    ORBFE_HIP_TRY(nullptr, hipSetDevice(cfg->device));
+    DeviceScope dev(cfg->device);
+    if (!dev.ok) CTX_FAIL((orbfe_ctx *)nullptr, ORBFE_ERR_HIP, "orbfe_create: hipSetDevice(%d) failed", cfg->device);
 
     orbfe_ctx *ctx = new orbfe_ctx();
     ctx->cfg = *cfg;
@@ -1304,7 +1321,8 @@ static int build_pyramid_impl(orbfe_ctx *ctx, const uint8_t *d_src, size_t pitch
         CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "build_pyramid: bad input geometry");
     if (n_frames > ctx->cfg.max_batch)
         CTX_FAIL(ctx, ORBFE_ERR_CAPACITY, "build_pyramid: n_frames %d > max_batch %d", n_frames, ctx->cfg.max_batch);
-    ORBFE_HIP_TRY(ctx->err, hipSetDevice(ctx->cfg.device));
+    DeviceScope dev(ctx->cfg.device);
+    if (!dev.ok) CTX_FAIL(ctx, ORBFE_ERR_HIP, "build_pyramid: hipSetDevice(%d) failed", ctx->cfg.device);
     const bool vec = (pitch % 4 == 0) && (frame_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_src) & 3u) == 0);
     if (rgb && !(vec && g.W % 4 == 0))
         CTX_FAIL(ctx, ORBFE_ERR_UNSUPPORTED, "build_pyramid_rgb: needs width %% 4 == 0 and a 4-byte aligned source "
@@ -1320,7 +1338,11 @@ static int build_pyramid_impl(orbfe_ctx *ctx, const uint8_t *d_src, size_t pitch
             hipLaunchKernelGGL(pyramid_fused_kernel<false>, dim3(tiles_x * tiles_y, n_frames), dim3(256), 0, S(stream),
                                g, ctx->d_pyr, d_src, (int)pitch, frame_stride, tiles_x, ctx->d_cellkey);
         next_level = 8;
-        ctx->cellkey_clean = n_frames; // the fused kernel cleared these frames' cell keys (same stream order)
+        // the fused kernel cleared these frames' cell keys; valid for a detect_batch issued next on
+        // this stream in the same capture mode
+        ctx->cellkey_clean = n_frames;
+        ctx->clean_stream = S(stream);
+        ctx->clean_capture = capture_id_of(S(stream));
     } else {
         dim3 grid(((g.W + 255) / 256) * ((g.H + 3) / 4), n_frames), block(256);
         if (vec)
@@ -1363,8 +1385,11 @@ int orbfe_detect_batch_shard(orbfe_ctx *ctx, int n_frames, int shard_index, int 
     if (n_frames > ctx->cfg.max_batch)
         CTX_FAIL(ctx, ORBFE_ERR_CAPACITY, "detect_batch: n_frames %d > max_batch %d", n_frames, ctx->cfg.max_batch);
     const DeviceGeom &g = ctx->g;
-    ORBFE_HIP_TRY(ctx->err, hipSetDevice(ctx->cfg.device));
-    if (ctx->cellkey_clean < n_frames) // not cleared by the pyramid kernel that just ran, or already used
+    DeviceScope dev(ctx->cfg.device);
+    if (!dev.ok) CTX_FAIL(ctx, ORBFE_ERR_HIP, "detect_batch: hipSetDevice(%d) failed", ctx->cfg.device);
+    const bool clean = ctx->cellkey_clean >= n_frames && ctx->clean_stream == S(stream) &&
+                       ctx->clean_capture == capture_id_of(S(stream));
+    if (!clean) // not cleared by the pyramid kernel that just ran on this stream, or already used
         ORBFE_HIP_TRY(ctx->err, hipMemsetAsync(ctx->d_cellkey, 0, (size_t)n_frames * g.K * sizeof(uint32_t), S(stream)));
     ctx->cellkey_clean = 0;
     // tiles shard_index, shard_index + shard_count, ... (interleaved: every shard gets a mix of
@@ -1387,6 +1412,7 @@ int orbfe_export_cell_keys(orbfe_ctx *ctx, int n_frames, uint32_t *d_keys, orbfe
     if (!ctx) return ORBFE_ERR_INVALID_ARG;
     if (!d_keys || n_frames < 1 || n_frames > ctx->cfg.max_batch)
         CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "export_cell_keys: bad argument");
+    DeviceScope dev(ctx->cfg.device);
     ORBFE_HIP_TRY(ctx->err, hipMemcpyAsync(d_keys, ctx->d_cellkey, (size_t)n_frames * ctx->g.K * sizeof(uint32_t),
                                            hipMemcpyDeviceToDevice, S(stream)));
     return ORBFE_OK;
@@ -1397,6 +1423,8 @@ int orbfe_import_cell_keys(orbfe_ctx *ctx, int n_frames, const uint32_t *d_keys,
     if (!ctx) return ORBFE_ERR_INVALID_ARG;
     if (!d_keys || n_frames < 1 || n_frames > ctx->cfg.max_batch)
         CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "import_cell_keys: bad argument");
+    DeviceScope dev(ctx->cfg.device);
+    ctx->cellkey_clean = 0;
     ORBFE_HIP_TRY(ctx->err, hipMemcpyAsync(ctx->d_cellkey, d_keys, (size_t)n_frames * ctx->g.K * sizeof(uint32_t),
                                            hipMemcpyDeviceToDevice, S(stream)));
     return ORBFE_OK;
@@ -1415,7 +1443,8 @@ int orbfe_describe_batch(orbfe_ctx *ctx, int n_frames, orbfe_keypoint *d_records
     const DeviceGeom &g = ctx->g;
     orbfe_soa so = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (soa) so = *soa;
-    ORBFE_HIP_TRY(ctx->err, hipSetDevice(ctx->cfg.device));
+    DeviceScope dev(ctx->cfg.device);
+    if (!dev.ok) CTX_FAIL(ctx, ORBFE_ERR_HIP, "describe_batch: hipSetDevice(%d) failed", ctx->cfg.device);
     hipLaunchKernelGGL(select_kernel, dim3(n_frames), dim3(kSelThreads), 0, S(stream), g, ctx->d_cellkey, ctx->d_sel,
                        ctx->d_selcount, d_counts, so);
     if (g.angle_in_radians)
@@ -1451,31 +1480,36 @@ int orbfe_extract_rgb(orbfe_ctx *ctx, const uint8_t *d_rgb, size_t pitch, size_t
     return rc;
 }
 
-int orbfe_match_batch(orbfe_ctx *ctx, const orbfe_keypoint *d_records, const int32_t *d_counts, int n_frames,
-                      int mode, int window, int max_distance, int32_t *d_idx, int32_t *d_dist,
+int orbfe_match_pairs(orbfe_ctx *ctx, const orbfe_keypoint *d_records, const int32_t *d_counts, int n_frames,
+                      int first, int stride, int mode, int window, int max_distance, int32_t *d_idx, int32_t *d_dist,
                       orbfe_stream_t stream)
 {
     if (!ctx) return ORBFE_ERR_INVALID_ARG;
     if (!d_records || !d_counts || !d_idx || n_frames < 1)
-        CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "match_batch: null argument");
-    if (mode != 0 && mode != 1) CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "match_batch: mode %d", mode);
-    if (mode == 0 && window < 0) CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "match_batch: reference mode needs window >= 0");
+        CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "match: null argument");
+    if (first < 0 || stride < 1) CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "match: first %d, stride %d", first, stride);
+    if (mode != 0 && mode != 1) CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "match: mode %d", mode);
+    if (mode == 0 && window < 0) CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "match: reference mode needs window >= 0");
     if (mode == 1 && ctx->g.cap > 65535) // packed (dist << 16 | index) key
-        CTX_FAIL(ctx, ORBFE_ERR_UNSUPPORTED, "match_batch: 256-bit mode supports at most 65535 keypoints per frame");
-    if (n_frames < 2) return ORBFE_OK;
+        CTX_FAIL(ctx, ORBFE_ERR_UNSUPPORTED, "match: 256-bit mode supports at most 65535 keypoints per frame");
+    // pairs (first + k * stride, first + k * stride + 1) with the curr frame inside the batch
+    const int n_pairs = n_frames - 2 - first >= 0 ? (n_frames - 2 - first) / stride + 1 : 0;
+    if (n_pairs < 1) return ORBFE_OK;
     const int cap = ctx->g.cap;
-    dim3 grid((cap + 255) / 256, n_frames - 1), block(256);
+    DeviceScope dev(ctx->cfg.device);
+    if (!dev.ok) CTX_FAIL(ctx, ORBFE_ERR_HIP, "match: hipSetDevice(%d) failed", ctx->cfg.device);
+    dim3 grid((cap + 255) / 256, n_pairs), block(256);
     if (mode == 0)
-        hipLaunchKernelGGL(match_batch_ref_kernel, grid, block, 0, S(stream), d_records, d_counts, cap,
+        hipLaunchKernelGGL(match_batch_ref_kernel, grid, block, 0, S(stream), d_records, d_counts, cap, first, stride,
                            (float)window, max_distance, d_idx, d_dist);
     else {
         if (n_frames > ctx->cfg.max_batch)
-            CTX_FAIL(ctx, ORBFE_ERR_CAPACITY, "match_batch: n_frames %d > max_batch %d", n_frames, ctx->cfg.max_batch);
+            CTX_FAIL(ctx, ORBFE_ERR_CAPACITY, "match: n_frames %d > max_batch %d", n_frames, ctx->cfg.max_batch);
         if (window < 0 && ctx->d_mexp) { // all candidates, <= 16384 per frame: matrix cores
             const int capP = ctx->cap_pad;
-            launch_match_mfma(d_records, d_counts, n_frames, cap, capP, max_distance, ctx->d_mexp, ctx->d_mkey, d_idx,
-                              d_dist, S(stream));
-            CTX_LAUNCH_CHECK(ctx, "match_batch");
+            launch_match_mfma(d_records, d_counts, n_frames, n_pairs, first, stride, cap, capP, max_distance, ctx->d_mexp,
+                              ctx->d_mkey, d_idx, d_dist, S(stream));
+            CTX_LAUNCH_CHECK(ctx, "match");
             return ORBFE_OK;
         }
         Desc8 *md = reinterpret_cast<Desc8 *>(ctx->d_mdesc);
@@ -1483,14 +1517,21 @@ int orbfe_match_batch(orbfe_ctx *ctx, const orbfe_keypoint *d_records, const int
         hipLaunchKernelGGL(match_gather_kernel, dim3((cap + 255) / 256, n_frames), block, 0, S(stream), d_records,
                            d_counts, cap, md, mp);
         if (window >= 0)
-            hipLaunchKernelGGL(match_batch_256_kernel<true>, grid, block, 0, S(stream), md, mp, d_counts, cap,
-                               window, max_distance, d_idx, d_dist);
+            hipLaunchKernelGGL(match_batch_256_kernel<true>, grid, block, 0, S(stream), md, mp, d_counts, cap, first,
+                               stride, window, max_distance, d_idx, d_dist);
         else
-            hipLaunchKernelGGL(match_batch_256_kernel<false>, grid, block, 0, S(stream), md, mp, d_counts, cap,
-                               window, max_distance, d_idx, d_dist);
+            hipLaunchKernelGGL(match_batch_256_kernel<false>, grid, block, 0, S(stream), md, mp, d_counts, cap, first,
+                               stride, window, max_distance, d_idx, d_dist);
     }
-    CTX_LAUNCH_CHECK(ctx, "match_batch");
+    CTX_LAUNCH_CHECK(ctx, "match");
     return ORBFE_OK;
+}
+
+int orbfe_match_batch(orbfe_ctx *ctx, const orbfe_keypoint *d_records, const int32_t *d_counts, int n_frames,
+                      int mode, int window, int max_distance, int32_t *d_idx, int32_t *d_dist,
+                      orbfe_stream_t stream)
+{
+    return orbfe_match_pairs(ctx, d_records, d_counts, n_frames, 0, 1, mode, window, max_distance, d_idx, d_dist, stream);
 }
 
 } // extern "C"

@@ -60,7 +60,7 @@ match_expand_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *_
     const int f = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
     const int i = t >> 3, w = t & 7; // 8 consecutive lanes = the 8 words of keypoint i
     if (i >= capP) return;
-    const bool live = i < counts[f];
+    const bool live = i < clamp_count(counts[f], cap);
     uint32_t word = 0;
     if (live) word = reinterpret_cast<const uint32_t *>(records + (size_t)f * cap + i)[5 + w];
     int pop = __popc(word);
@@ -75,14 +75,16 @@ match_expand_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *_
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
 match_mfma_kernel(const uint4 *__restrict__ mexp, const float *__restrict__ mkey, const int32_t *__restrict__ counts,
-                  int cap, int capP, int max_dist, int32_t *__restrict__ out_idx, int32_t *__restrict__ out_dist)
+                  int cap, int capP, int first, int stride, int max_dist, int32_t *__restrict__ out_idx,
+                  int32_t *__restrict__ out_dist)
 {
     // the candidate ring while the MFMA loop runs, then (after a barrier) the partial maxima
     __shared__ __attribute__((aligned(16))) unsigned char s_mem[kMmaLdsBytes];
     float *s_best = reinterpret_cast<float *>(s_mem);
-    int p, blk;
-    xcd_remap(gridDim.x, gridDim.y, &p, &blk); // all query blocks of a pair share one L2
-    const int nA = counts[p], nB = counts[p + 1];
+    int pk, blk;
+    xcd_remap(gridDim.x, gridDim.y, &pk, &blk); // all query blocks of a pair share one L2
+    const int p = first + pk * stride;
+    const int nA = clamp_count(counts[p], cap), nB = clamp_count(counts[p + 1], cap);
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform: block indices stay in SGPRs
     const int row0 = blk * kMmaRows;
@@ -213,20 +215,21 @@ match_mfma_kernel(const uint4 *__restrict__ mexp, const float *__restrict__ mkey
             bd = pop_a + (nk >> 14);
             ok = bd <= max_dist;
         }
-        out_idx[(size_t)p * cap + i] = ok ? bj : -1;
-        if (out_dist) out_dist[(size_t)p * cap + i] = ok ? bd : -1;
+        out_idx[(size_t)pk * cap + i] = ok ? bj : -1;
+        if (out_dist) out_dist[(size_t)pk * cap + i] = ok ? bd : -1;
     }
 }
 
 
-void launch_match_mfma(const orbfe_keypoint *d_records, const int32_t *d_counts, int n_frames, int cap, int capP,
-                       int max_dist, uint4 *mexp, float *mkey, int32_t *d_idx, int32_t *d_dist, hipStream_t stream)
+void launch_match_mfma(const orbfe_keypoint *d_records, const int32_t *d_counts, int n_frames, int n_pairs, int first,
+                       int stride, int cap, int capP, int max_dist, uint4 *mexp, float *mkey, int32_t *d_idx,
+                       int32_t *d_dist, hipStream_t stream)
 {
     static_assert(kMmaS == kMmaMaxKeypoints, "key packing");
     hipLaunchKernelGGL(match_expand_kernel, dim3((capP * 8 + 255) / 256, n_frames), dim3(256), 0, stream, d_records,
                        d_counts, cap, capP, mexp, mkey);
-    hipLaunchKernelGGL(match_mfma_kernel, dim3((capP + kMmaRows - 1) / kMmaRows, n_frames - 1), dim3(256), 0, stream,
-                       mexp, mkey, d_counts, cap, capP, max_dist, d_idx, d_dist);
+    hipLaunchKernelGGL(match_mfma_kernel, dim3((capP + kMmaRows - 1) / kMmaRows, n_pairs), dim3(256), 0, stream,
+                       mexp, mkey, d_counts, cap, capP, first, stride, max_dist, d_idx, d_dist);
 }
 
 } // namespace orbfe

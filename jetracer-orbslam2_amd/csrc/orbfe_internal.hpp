@@ -145,10 +145,36 @@ struct DeviceGeom { // passed by value to kernels
     LevelInfo lv[kMaxLevels];
 };
 
-// match_mfma.hip: 256-bit brute-force matching of frames f-1 -> f on the matrix cores
+// match_mfma.hip: 256-bit brute-force matching on the matrix cores; pair k = frames
+// (first + k * stride, first + k * stride + 1), results at k * cap
 constexpr int kMmaMaxKeypoints = 16384;
-void launch_match_mfma(const orbfe_keypoint *d_records, const int32_t *d_counts, int n_frames, int cap, int capP,
-                       int max_dist, uint4 *mexp, float *mkey, int32_t *d_idx, int32_t *d_dist, hipStream_t stream);
+void launch_match_mfma(const orbfe_keypoint *d_records, const int32_t *d_counts, int n_frames, int n_pairs, int first,
+                       int stride, int cap, int capP, int max_dist, uint4 *mexp, float *mkey, int32_t *d_idx,
+                       int32_t *d_dist, hipStream_t stream);
+
+// a per-frame count read from a caller's device buffer, made safe to index with: a stale or corrupt
+// count must not walk past the frame's cap records
+__host__ __device__ inline int clamp_count(int n, int cap)
+{
+    return n < 0 ? 0 : (n > cap ? cap : n);
+}
+
+// Makes `device` current for the duration of a call and restores the caller's device on return.
+struct DeviceScope {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceScope(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) ok = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceScope()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
 
 } // namespace orbfe
 
@@ -165,6 +191,8 @@ struct orbfe_ctx {
     float *d_mkey = nullptr;        // [max_batch][cap_pad]     MFMA matcher: -(popcount * 16384 + index)
     int cap_pad = 0;                // cap rounded up to 16
     int cellkey_clean = 0;          // frames whose cell keys the last pyramid build left cleared (0 once detect ran)
+    hipStream_t clean_stream = nullptr;      // ... on this stream
+    unsigned long long clean_capture = 0;    // ... in this graph capture (0 = eager)
     uint4 *d_momw = nullptr;        // describe: int8 weight fragments of the moment MFMAs (make_moment_weights)
     orbfe::TileDesc *d_tiles = nullptr;
     int n_tiles = 0;

@@ -108,6 +108,8 @@ _SIGS = {
                                 C.c_void_p, C.c_void_p, C.POINTER(Soa), C.c_void_p]),
     "orbfe_match_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "orbfe_match_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "orbfe_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "orbfe_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "orbfe_stream_sync": (C.c_int, [C.c_void_p]),
@@ -223,6 +225,11 @@ class Context:
     def match_batch(self, d_records, d_counts, n_frames, mode, window, max_distance, d_idx,
                     d_dist=None, stream=0):
         check(lib().orbfe_match_batch(self.handle, d_records, d_counts, n_frames, mode, window,
+                                      max_distance, d_idx, d_dist, stream), self.handle)
+
+    def match_pairs(self, d_records, d_counts, n_frames, first, stride, mode, window, max_distance, d_idx,
+                    d_dist=None, stream=0):
+        check(lib().orbfe_match_pairs(self.handle, d_records, d_counts, n_frames, first, stride, mode, window,
                                       max_distance, d_idx, d_dist, stream), self.handle)
 
     def read_level(self, level, frame=0, stream=0):

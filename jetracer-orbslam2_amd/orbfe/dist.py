@@ -2,12 +2,127 @@
 
 Frames are independent units, so a batch is split into contiguous blocks, one per rank (one
 process per GPU); images never cross GPUs.  The only exchange step is a gather of the
-fixed-stride keypoint records and per-frame counts to rank 0 -- torch.distributed backend
-"nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.  Matching pairs (t-1, t) stay on
-one rank because shards are cut on frame boundaries and each rank matches inside its block.
+keypoint records and per-frame counts to rank 0.  Matching pairs (t-1, t) stay on one rank
+because shards are cut on frame boundaries and each rank matches inside its block.
+
+Two implementations of the same exchange:
+  * RcclComm -- the product path: liborbfe_dist.so (include/orbfe_dist.h), C++ host code on RCCL
+    (ncclCommInitRank, grouped ncclSend / ncclRecv, ncclAllReduce) with its own communication
+    stream.  bench.py uses it on GPUs.
+  * gather_keypoints / merge_cell_keys over torch.distributed -- the rehearsal: backend "gloo" in
+    the CPU tests and when several ranks share one GPU (RCCL refuses two ranks on one device).
 """
+import ctypes as C
+import os
+
 import torch
 import torch.distributed as dist
+
+DIST_LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "liborbfe_dist.so")
+DIST_ID_BYTES = 128
+
+_DIST_SIGS = {
+    "orbfe_dist_unique_id": (C.c_int, [C.c_void_p]),
+    "orbfe_dist_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "orbfe_dist_destroy": (None, [C.c_void_p]),
+    "orbfe_dist_rank": (C.c_int, [C.c_void_p]),
+    "orbfe_dist_world": (C.c_int, [C.c_void_p]),
+    "orbfe_dist_last_error": (C.c_char_p, [C.c_void_p]),
+    "orbfe_dist_shard_range": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "orbfe_dist_gather_keypoints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                              C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "orbfe_dist_allreduce_max_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "orbfe_dist_wait": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "orbfe_dist_ticket": (C.c_int64, [C.c_void_p]),
+    "orbfe_dist_wait_ticket": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "orbfe_dist_sync": (C.c_int, [C.c_void_p]),
+    "orbfe_dist_host_allreduce": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int]),
+    "orbfe_dist_barrier": (C.c_int, [C.c_void_p]),
+}
+DIST_EXPORTS = tuple(_DIST_SIGS)  # every symbol include/orbfe_dist.h declares
+_dist_lib = None
+
+
+def dist_lib():
+    """Load liborbfe_dist.so (RCCL + HIP); raises if it has not been built."""
+    global _dist_lib
+    if _dist_lib is None:
+        if not os.path.exists(DIST_LIB_PATH):
+            raise RuntimeError("liborbfe_dist.so not found at %s: build it with `make -C jetracer-orbslam2_amd/csrc`"
+                               % DIST_LIB_PATH)
+        L = C.CDLL(DIST_LIB_PATH)
+        for name, (res, args) in _DIST_SIGS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _dist_lib = L
+    return _dist_lib
+
+
+class RcclComm:
+    """One rank of the C++/RCCL communicator of include/orbfe_dist.h.
+
+    `exchange_id(id_bytes_or_None) -> bytes` hands rank 0's unique id to every rank (the side
+    channel is the application's: bench.py uses torch.distributed's store)."""
+
+    def __init__(self, rank, world, device, exchange_id):
+        L = dist_lib()
+        ident = None
+        if rank == 0:
+            buf = (C.c_uint8 * DIST_ID_BYTES)()
+            self._check(L.orbfe_dist_unique_id(buf), None)
+            ident = bytes(buf)
+        ident = exchange_id(ident)
+        assert len(ident) == DIST_ID_BYTES
+        h = C.c_void_p()
+        idbuf = (C.c_uint8 * DIST_ID_BYTES).from_buffer_copy(ident)
+        self._check(L.orbfe_dist_create(idbuf, rank, world, device, C.byref(h)), None)
+        self.handle, self.rank, self.world = h, rank, world
+
+    @staticmethod
+    def _check(code, handle):
+        if code != 0:
+            raise RuntimeError("orbfe_dist error %d: %s" % (code, dist_lib().orbfe_dist_last_error(handle).decode()))
+
+    def gather_keypoints(self, records, counts, n_frames, cap, all_records, all_counts, root, exact, stream):
+        """Pointers are device addresses (ints); all_* may be None off the root."""
+        self._check(dist_lib().orbfe_dist_gather_keypoints(self.handle, records, counts, n_frames, cap, all_records,
+                                                           all_counts, root, int(bool(exact)), stream), self.handle)
+
+    def allreduce_max_keys(self, keys, n, stream):
+        self._check(dist_lib().orbfe_dist_allreduce_max_keys(self.handle, keys, n, stream), self.handle)
+
+    def wait(self, stream):
+        self._check(dist_lib().orbfe_dist_wait(self.handle, stream), self.handle)
+
+    def ticket(self):
+        return int(dist_lib().orbfe_dist_ticket(self.handle))
+
+    def wait_ticket(self, ticket, stream):
+        self._check(dist_lib().orbfe_dist_wait_ticket(self.handle, ticket, stream), self.handle)
+
+    def sync(self):
+        self._check(dist_lib().orbfe_dist_sync(self.handle), self.handle)
+
+    def host_allreduce(self, values, op="max"):
+        arr = (C.c_double * len(values))(*values)
+        self._check(dist_lib().orbfe_dist_host_allreduce(self.handle, arr, len(values), 0 if op == "max" else 1),
+                    self.handle)
+        return list(arr)
+
+    def barrier(self):
+        self._check(dist_lib().orbfe_dist_barrier(self.handle), self.handle)
+
+    def close(self):
+        if self.handle:
+            dist_lib().orbfe_dist_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def shard_range(n_total, rank, world):
