@@ -237,6 +237,11 @@ def main():
     if args.dry_run:
         print(json.dumps([]))
         return
+    # stdout carries exactly ONE line, the JSON: whatever libraries print there (gloo's connection
+    # banner, RCCL notices) is sent to stderr for the rest of the run
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -554,8 +559,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
-        sys.stdout.flush()
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
 
 
 if __name__ == "__main__":
