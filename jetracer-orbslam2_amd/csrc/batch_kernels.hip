@@ -238,10 +238,10 @@ pyramid_fused_kernel(DeviceGeom g, uint8_t *__restrict__ pyr, const uint8_t *__r
 // one frame.  Most pixels are not corners, so the work is staged to keep the lanes busy:
 //   A  load the pixel tile (4-px halo: ring radius 3 + NMS radius 1) into LDS as dwords
 //   B  compass pre-test on 4 pixels per lane with packed-u16 min/max: a cyclic arc of >= 9
-//      (>= 12) ring pixels covers >= 2 (>= 3) of the 4 compass pixels N,E,S,W, so the 2nd
-//      (3rd) largest of them must be brighter than c + t, or the 2nd (3rd) smallest darker
-//      than c - t.  Survivors are compacted into an LDS queue.  (Pure work-skipping, like
-//      the reference's opposite-pair prechecks, fast.cu:98-124: it rejects no corner.)
+//      ring pixels holds one pixel of each opposite pair (N,S) and (E,W), one of >= 12 holds
+//      3 of the 4 compass pixels.  Survivors are compacted into an LDS queue.  (Pure
+//      work-skipping, like the reference's opposite-pair prechecks, fast.cu:98-124: it rejects
+//      no corner.)
 //   C  full 16-pixel ring test on queued candidates only, two ring pixels per packed-u16
 //      op (saturating subtracts give the score terms and the label flags at once); scores
 //      go to a u16 LDS tile; positive scores inside the tile are queued again
@@ -274,8 +274,15 @@ __device__ inline uint32_t compass4(uint32_t C, uint32_t Wd, uint32_t Ed, uint32
         const us2 hi = c + U2(t2), lo = ssub(c, U2(t2));
         const us2 a = pmax(n, s), b = pmin(n, s), cc = pmax(e, w), d = pmin(e, w);
         const us2 m1 = pmin(a, cc), m2 = pmax(b, d);
-        const us2 s2 = pmax(m1, m2), s3 = pmin(m1, m2); // 2nd and 3rd largest of the four
-        const us2 bv = need3 ? s3 : s2, dv = need3 ? s2 : s3;
+        // arc >= 12 (need3): 3 of the 4 compass pixels lie in the arc, so the 3rd largest must be brighter
+        // or the 3rd smallest (= 2nd largest) darker.  arc 9..11: the arc leaves at most 7 contiguous ring
+        // pixels out, so it holds one pixel of EVERY opposite pair: max(N,S) and max(E,W) both brighter
+        // (m1), or min(N,S) and min(E,W) both darker (m2) -- tighter than "2 of 4" and two ops less
+        us2 bv = m1, dv = m2;
+        if (need3) {
+            bv = pmin(m1, m2);
+            dv = pmax(m1, m2);
+        }
         uint32_t f = U1(ssub(bv, hi)) | U1(ssub(lo, dv)); // 16-bit lane != 0 <=> candidate
         asm("v_pk_min_u16 %0, %1, %2" : "=v"(f) : "v"(f), "v"(0x00010001u)); // lanes -> 0 / 1
         out |= f << h; // h = 0: bits 0 and 16 (pixels 0, 2); h = 1: bits 1 and 17 (pixels 1, 3)
@@ -536,7 +543,7 @@ constexpr int kSelThreads = 1024; // one workgroup per frame: wide, because the 
 constexpr int kSelWaves = kSelThreads / 64;
 
 __global__ void __launch_bounds__(kSelThreads)
-select_kernel(DeviceGeom g, const uint32_t *__restrict__ cellkey, uint4 *__restrict__ sel,
+select_kernel(DeviceGeom g, const uint32_t *__restrict__ cellkey, uint4 *__restrict__ sel, uint16_t *__restrict__ cellslot,
               int32_t *__restrict__ selcount, int32_t *__restrict__ counts_out, orbfe_soa soa)
 {
     constexpr int kBinsPer = 4096 / kSelThreads; // score bins owned by one thread
@@ -622,8 +629,9 @@ select_kernel(DeviceGeom g, const uint32_t *__restrict__ cellkey, uint4 *__restr
         const int slot = block_excl_scan<kSelWaves>(keep, s_wave, &keep_tot);
         int s = 0, l = 0, x = 0, y = 0;
         const bool want_soa = soa.d_pos || soa.d_score || soa.d_level || soa.d_angle || soa.d_desc || soa.d_desc32;
-        if (keep || (in && want_soa)) nms_decode(key, k % g.cells_x, k / g.cells_x, g.cell, &s, &l, &x, &y);
-        if (keep) sel[(size_t)f * g.cap + n_sel + slot] = make_uint4((uint32_t)k, (uint32_t)x | ((uint32_t)y << 16), key, 0u);
+        if ((keep && sel) || (in && want_soa)) nms_decode(key, k % g.cells_x, k / g.cells_x, g.cell, &s, &l, &x, &y);
+        if (keep && sel) sel[(size_t)f * g.cap + n_sel + slot] = make_uint4((uint32_t)k, (uint32_t)x | ((uint32_t)y << 16), key, 0u);
+        if (in) cellslot[(size_t)f * g.K + k] = keep ? (uint16_t)(n_sel + slot) : (uint16_t)0xFFFFu; // cap <= 65535
         if (in && want_soa) {
             const size_t o = (size_t)f * g.K + k;
             if (soa.d_pos) {
@@ -907,6 +915,248 @@ describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__re
             }
             if (soa.d_angle || soa.d_desc32 || soa.d_desc) {
                 const size_t o = (size_t)f * g.K + kcell[it];
+                if (soa.d_angle) soa.d_angle[o] = angle;
+                if (soa.d_desc32) soa.d_desc32[o] = orb_compress(d);
+                if (soa.d_desc) {
+                    uint32_t *sd = reinterpret_cast<uint32_t *>(soa.d_desc + 32 * o);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        sd[2 * k] = (uint32_t)d[k];
+                        sd[2 * k + 1] = (uint32_t)(d[k] >> 32);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// a8 + a9 + a10 fused, tile form: one workgroup = one 64x64 level-0 tile of one frame and every
+// selected keypoint whose cell lies in it (at most one per cell, so <= (64 / cell)^2 <= 64).
+// The tile plus its R-pixel halo is staged in LDS ONCE (LDS-DMA, 16-byte chunks) and shared by
+// all its keypoints: ~330 staged bytes per keypoint on the bench scenes instead of a private
+// 1488-byte patch each, no per-keypoint staging latency, and 9 KB of LDS per workgroup instead
+// of 24, so eight workgroups fit a CU.  The keypoint list is read straight from the cell keys
+// and the cell -> slot map select_kernel wrote; records go to their slots, so the output is the
+// same cell-ordered array as before.
+// Pixels the reference's moment loops exclude (row <= 0, row >= H, column <= 0, column >= W:
+// orb.cu:98,112,119) are staged as 0; the descriptor never samples them (17 / 19-px guard band).
+// ------------------------------------------------------------------------------------
+constexpr int kDTile = 64;
+
+template <int R>
+struct TileGeom {
+    static constexpr int kHaloX = (R + 15) / 16 * 16;                 // 16 (R = 15) / 32 (R = 19): chunk-aligned
+    static constexpr int kPitch = kDTile + 2 * kHaloX;                // 96 / 128 bytes
+    static constexpr int kRows = kDTile + 2 * R;                      // 94 / 102
+    static constexpr int kChunksRow = kPitch / 16;
+    static constexpr int kChunks = kRows * kChunksRow;                // 564 / 816
+    static constexpr int kBytes = kChunks * 16;
+    static constexpr int kPad = 256;                                  // zero-weighted moment reads past the last row
+    static constexpr int kTrips = (kChunks + 255) / 256;              // DMA instructions per thread
+    // Moments on the matrix cores: one v_mfma_i32_16x16x64_i8 row = (keypoint, slice s), its 64
+    // K-bytes = columns 0..31 of TWO consecutive rows of the keypoint's 31-row disc box (lane chunk
+    // c: row 8 ks + 2 s + (c >> 1), bytes 16 (c & 1) ..); 4 slices x 2 rows = 8 rows per step, so
+    // kMom = 4 steps cover rows 0..31 (row 31 and column 31 carry zero weight).
+    static constexpr int kMom = 4;
+    static_assert((63 + R - 15 + 31) * kPitch + 63 + kHaloX - 15 + 32 <= kBytes + kPad, "moment reads stay inside the tile array");
+};
+
+// B operand of the tile kernel's moment MFMAs, [kMom][lane 64][16]: lane = 16 * chunk + column,
+// column = 2 * slice + (0: dx weights, 1: dy weights), columns 8..15 zero.  Disc chords: orb.cu:79-80.
+static std::vector<int8_t> make_tile_moment_weights()
+{
+    static const int u[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 7, 5, 0};
+    std::vector<int8_t> w((size_t)4 * 64 * 16, 0);
+    for (int ks = 0; ks < 4; ks++)
+        for (int lane = 0; lane < 64; lane++) {
+            const int col = lane & 15, c = lane >> 4;
+            if (col >= 8) continue;
+            const int sl = col >> 1, xy = col & 1;
+            for (int j = 0; j < 16; j++) {
+                const int row = 8 * ks + 2 * sl + (c >> 1), bx = 16 * (c & 1) + j;
+                const int dy = row - 15, dx = bx - 15;
+                const int ady = dy < 0 ? -dy : dy, adx = dx < 0 ? -dx : dx;
+                if (ady <= 15 && adx <= 15 && adx <= u[ady]) w[((size_t)ks * 64 + lane) * 16 + j] = (int8_t)(xy ? dy : dx);
+            }
+        }
+    return w;
+}
+
+template <int R>
+__global__ void __launch_bounds__(256)
+describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32_t *__restrict__ cellkey,
+                     const uint16_t *__restrict__ cellslot, const uint4 *__restrict__ momw, int tiles_x,
+                     orbfe_keypoint *__restrict__ records, orbfe_soa soa)
+{
+    using G = TileGeom<R>;
+    constexpr int P = G::kPitch;
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[G::kBytes + G::kPad];
+    __shared__ uint32_t s_kxy[64], s_kkey[64], s_kslot[64]; // the tile's keypoints: x | y << 16, key, record slot
+    __shared__ int s_mom[128];                               // their moments: m10, m01
+    __shared__ float s_ang[64], s_cos[64], s_sin[64];        // angle and steering (cos, sin)
+    __shared__ int s_nkp;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int f, tile;
+    xcd_remap(gridDim.x, gridDim.y, &f, &tile);
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int x0 = tx * kDTile, y0 = ty * kDTile;
+    const int ox = x0 - G::kHaloX, oy = y0 - R; // image position of tile byte (0, 0)
+    const uint8_t *img = pyr + (size_t)f * g.frame_stride + g.lv[0].offset;
+    const int IP = g.lv[0].pitch;
+
+    // ---- stage the tile: chunk q = (row q / kChunksRow, 16-byte column q % kChunksRow) lands at LDS byte 16 q.
+    //      Addresses are clamped into the image (rows) and the padded pitch (columns): every load is
+    //      legal, and what lies outside the image is zeroed afterwards (border tiles only).
+#pragma unroll
+    for (int t = 0; t < G::kTrips; t++) {
+        const int q = 256 * t + tid;
+        if (256 * (t + 1) <= G::kChunks || q < G::kChunks) {
+            const int r = q / G::kChunksRow, cc = q - r * G::kChunksRow;
+            int gy = oy + r, gx = ox + 16 * cc;
+            gy = gy < 0 ? 0 : (gy >= g.H ? g.H - 1 : gy);
+            gx = gx < 0 ? 0 : (gx > IP - 16 ? IP - 16 : gx);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(img + (uint32_t)(__mul24(gy, IP) + gx)),
+                                             (__attribute__((address_space(3))) void *)(s_tile + 16 * (256 * t + 64 * wv)), 16, 0, 0);
+        }
+    }
+    if (tid < 128) s_mom[tid] = 0;
+    // ---- the tile's keypoints (wave 0, while the DMAs fly): one lane per cell of the tile
+    const int n = kDTile / g.cell; // cells per tile edge: 8, 4, 2 or 1
+    if (wv == 0) {
+        const int cxl = lane & (n - 1), cyl = lane >> ilog2(n);
+        const int cx = tx * n + cxl, cy = ty * n + cyl;
+        const bool valid = lane < n * n && cx < g.cells_x && cy < g.cells_y;
+        const int k = cy * g.cells_x + cx;
+        uint32_t slot = 0xFFFFu, key = 0;
+        if (valid) {
+            slot = cellslot[(size_t)f * g.K + k];
+            key = cellkey[(size_t)f * g.K + k];
+        }
+        const bool keep = valid && slot != 0xFFFFu;
+        const uint64_t m = __ballot(keep);
+        if (keep) {
+            int sc, lv, x, y;
+            nms_decode(key, cx, cy, g.cell, &sc, &lv, &x, &y);
+            const int pos = (int)__popcll(m & ((1ull << lane) - 1ull));
+            s_kxy[pos] = (uint32_t)x | ((uint32_t)y << 16);
+            s_kkey[pos] = key;
+            s_kslot[pos] = slot; // the cell index is recomputed from (x, y) where the SoA view needs it
+        }
+        if (lane == 0) s_nkp = (int)__popcll(m);
+    }
+    // LDS-DMA data is ordered only behind the issuing wave's vmcnt; then the barrier publishes it
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int nkp = s_nkp;
+    if (nkp == 0) return; // uniform
+    // ---- border tiles: zero what the moments exclude / what lies outside the image
+    if (ox <= 0 || ox + P > g.W || oy <= 0 || oy + G::kRows > g.H) { // uniform
+        uint32_t *t32 = reinterpret_cast<uint32_t *>(s_tile);
+        for (int i = tid; i < G::kBytes / 4; i += 256) {
+            const int r = i / (P / 4), c4 = i - r * (P / 4);
+            const int gy = oy + r, gx = ox + 4 * c4;
+            uint32_t keep = 0xFFFFFFFFu;
+            if (gy <= 0 || gy >= g.H) keep = 0u;
+            else {
+                // byte j is kept iff 0 < gx + j < W
+                int lo = 1 - gx, hi = g.W - gx; // j in [lo, hi)
+                lo = lo < 0 ? 0 : (lo > 4 ? 4 : lo);
+                hi = hi < 0 ? 0 : (hi > 4 ? 4 : hi);
+                const uint32_t mlo = lo >= 4 ? 0u : (0xFFFFFFFFu << (8 * lo));
+                const uint32_t mhi = hi >= 4 ? 0xFFFFFFFFu : ((1u << (8 * hi)) - 1u);
+                keep = hi > lo ? (mlo & mhi) : 0u;
+            }
+            if (keep != 0xFFFFFFFFu) t32[i] = keep ? (t32[i] & keep) : 0u;
+        }
+        __syncthreads();
+    }
+    // weight fragments of the moment MFMAs and this lane's four rBRIEF pattern rows
+    uint4 bw[G::kMom];
+#pragma unroll
+    for (int ks = 0; ks < G::kMom; ks++) bw[ks] = momw[ks * 64 + lane];
+    float4 pat[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) pat[r] = reinterpret_cast<const float4 *>(c_pattern_f)[64 * r + lane];
+    const uint32_t tile_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t *)s_tile;
+
+    // ---- phase A: moments of groups of kKpw keypoints on the matrix cores -> s_m10 / s_m01
+    for (int grp = wv; grp * kKpw < nkp; grp += 4) { // uniform
+        const int k0 = grp * kKpw;
+        const int nk = nkp - k0 < kKpw ? nkp - k0 : kKpw;
+        // A fragment of lane (chunk c, row = keypoint + 4 * slice) = 16 bytes of disc-box row
+        // 8 ks + 2 slice + (c >> 1), columns 16 (c & 1) .. + 15, read at the keypoint's own byte
+        // position (a misaligned ds_read_b128, which gfx950 serves)
+        const int row = lane & 15, c = lane >> 4;
+        const int j = k0 + ((row & 3) < nk ? (row & 3) : nk - 1);
+        const uint32_t xy = s_kxy[j];
+        const int kb = ((int)(xy >> 16) - 15 - oy) * P + (int)(xy & 0xFFFFu) - 15 - ox;
+        const uint32_t aaddr = tile_lds + (uint32_t)(kb + (2 * (row >> 2) + (c >> 1)) * P + 16 * (c & 1));
+        u32x4 av[G::kMom];
+#pragma unroll
+        for (int ks = 0; ks < G::kMom; ks++) // the waits are per read (in-flight registers never leave an asm block)
+            asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(av[ks]) : "v"(aaddr), "n"(ks * 8 * P) : "memory");
+        v4i acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < G::kMom; ks++) {
+            const uint4 bv = bw[ks];
+            const v4i a = {(int)(av[ks].x ^ 0x80808080u), (int)(av[ks].y ^ 0x80808080u), (int)(av[ks].z ^ 0x80808080u),
+                           (int)(av[ks].w ^ 0x80808080u)};
+            const v4i b = {(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w};
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc, 0, 0, 0);
+        }
+        // D[row][col] sits in lane 16 * (row / 4) + col, register row % 4: keypoint `it`, slice s, weights xy
+        // -> register `it` of lane 18 s + xy.  The four slices meet in LDS: lanes 18 s + xy add register `it`
+        // into s_mom[2 (k0 + it) + xy] (4 adders per word, LDS atomics: integer, order-free)
+        const int sl = lane >> 4, cxy = (lane & 15) - 2 * sl; // this lane's slice and column offset inside it
+        if (cxy == 0 || cxy == 1) {
+#pragma unroll
+            for (int it = 0; it < kKpw; it++)
+                if (it < nk) atomicAdd(&s_mom[2 * (k0 + it) + cxy], acc[it]);
+        }
+    }
+    __syncthreads();
+    // ---- phase B: one lane per keypoint: atan2f and the steering cos / sin, ONCE per tile
+    if (wv == 0 && lane < nkp) {
+        const float ang = orbfe_atan2f((float)s_mom[2 * lane + 1], (float)s_mom[2 * lane]);
+        float ca, sb;
+        orb_steer(ang, g.angle_in_radians, &ca, &sb);
+        s_ang[lane] = ang;
+        s_cos[lane] = ca;
+        s_sin[lane] = sb;
+    }
+    __syncthreads();
+    // ---- phase C: descriptors + records, keypoints dealt round-robin to the waves
+    for (int j = wv; j < nkp; j += 4) { // uniform
+        const uint32_t xy = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_kxy[j]);
+        const uint32_t key = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_kkey[j]);
+        const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_kslot[j]);
+        const float angle = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_ang[j])));
+        const float a = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_cos[j])));
+        const float b = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_sin[j])));
+        const int x = (int)(xy & 0xFFFFu), y = (int)(xy >> 16);
+        uint64_t d[4] = {0, 0, 0, 0};
+        if (!orb_border_zero(x, y, g.W, g.H, g.angle_in_radians))
+            orb_describe_lds<P>(s_tile, (y - oy) * P + x - ox, a, b, pat, d);
+        // every value is wave-uniform: lane 0 stores the 13 dwords of the record
+        if (lane == 0) {
+            const int score = (int)(key >> 15), level = 7 - (int)((key >> 12) & 7u);
+            uint32_t *rec = reinterpret_cast<uint32_t *>(records + (size_t)f * g.cap + slot);
+            rec[0] = __float_as_uint((float)x);
+            rec[1] = __float_as_uint((float)y);
+            rec[2] = __float_as_uint((float)score);
+            rec[3] = (uint32_t)level;
+            rec[4] = __float_as_uint(angle);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                rec[5 + 2 * k] = (uint32_t)d[k];
+                rec[6 + 2 * k] = (uint32_t)(d[k] >> 32);
+            }
+            if (soa.d_angle || soa.d_desc32 || soa.d_desc) {
+                const int cell = (y / g.cell) * g.cells_x + x / g.cell;
+                const size_t o = (size_t)f * g.K + cell;
                 if (soa.d_angle) soa.d_angle[o] = angle;
                 if (soa.d_desc32) soa.d_desc32[o] = orb_compress(d);
                 if (soa.d_desc) {
@@ -1254,6 +1504,7 @@ int orbfe_create(const orbfe_config *cfg, orbfe_ctx **out)
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_cellkey, B * g.K * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_sel, B * g.cap * sizeof(uint4));
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_selcount, B * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_cellslot, B * g.K * sizeof(uint16_t));
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_mdesc, B * g.cap * 32);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_mpos, B * g.cap * 8);
     ctx->cap_pad = (g.cap + 15) / 16 * 16;
@@ -1261,6 +1512,13 @@ int orbfe_create(const orbfe_config *cfg, orbfe_ctx **out)
         const std::vector<int8_t> w = make_moment_weights(g.angle_in_radians ? 19 : 15);
         if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_momw, w.size());
         if (e == hipSuccess) e = hipMemcpy(ctx->d_momw, w.data(), w.size(), hipMemcpyHostToDevice);
+        const std::vector<int8_t> wt = make_tile_moment_weights();
+        if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_momw_tile, wt.size());
+        if (e == hipSuccess) e = hipMemcpy(ctx->d_momw_tile, wt.data(), wt.size(), hipMemcpyHostToDevice);
+    }
+    {
+        const char *v = getenv("ORBFE_DESCRIBE"); // A/B timing of the two describe kernels on one box
+        ctx->describe_patch = v && !strcmp(v, "patch");
     }
     if (g.cap <= kMmaMaxKeypoints) { // scratch of the matrix-core matcher
         if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_mexp, B * ctx->cap_pad * 128);
@@ -1285,6 +1543,8 @@ void orbfe_destroy(orbfe_ctx *ctx)
     if (ctx->d_cellkey) (void)hipFree(ctx->d_cellkey);
     if (ctx->d_sel) (void)hipFree(ctx->d_sel);
     if (ctx->d_selcount) (void)hipFree(ctx->d_selcount);
+    if (ctx->d_cellslot) (void)hipFree(ctx->d_cellslot);
+    if (ctx->d_momw_tile) (void)hipFree(ctx->d_momw_tile);
     if (ctx->d_tiles) (void)hipFree(ctx->d_tiles);
     if (ctx->d_mdesc) (void)hipFree(ctx->d_mdesc);
     if (ctx->d_mpos) (void)hipFree(ctx->d_mpos);
@@ -1445,14 +1705,24 @@ int orbfe_describe_batch(orbfe_ctx *ctx, int n_frames, orbfe_keypoint *d_records
     if (soa) so = *soa;
     DeviceScope dev(ctx->cfg.device);
     if (!dev.ok) CTX_FAIL(ctx, ORBFE_ERR_HIP, "describe_batch: hipSetDevice(%d) failed", ctx->cfg.device);
-    hipLaunchKernelGGL(select_kernel, dim3(n_frames), dim3(kSelThreads), 0, S(stream), g, ctx->d_cellkey, ctx->d_sel,
-                       ctx->d_selcount, d_counts, so);
-    if (g.angle_in_radians)
-        hipLaunchKernelGGL(describe_kernel<19>, dim3((g.cap + 4 * kKpw - 1) / (4 * kKpw), n_frames), dim3(256), 0,
-                           S(stream), g, ctx->d_pyr, ctx->d_sel, ctx->d_selcount, ctx->d_momw, d_records, so);
-    else
-        hipLaunchKernelGGL(describe_kernel<15>, dim3((g.cap + 4 * kKpw - 1) / (4 * kKpw), n_frames), dim3(256), 0,
-                           S(stream), g, ctx->d_pyr, ctx->d_sel, ctx->d_selcount, ctx->d_momw, d_records, so);
+    hipLaunchKernelGGL(select_kernel, dim3(n_frames), dim3(kSelThreads), 0, S(stream), g, ctx->d_cellkey,
+                       ctx->describe_patch ? ctx->d_sel : nullptr, ctx->d_cellslot, ctx->d_selcount, d_counts, so);
+    if (ctx->describe_patch) {
+        if (g.angle_in_radians)
+            hipLaunchKernelGGL(describe_kernel<19>, dim3((g.cap + 4 * kKpw - 1) / (4 * kKpw), n_frames), dim3(256), 0,
+                               S(stream), g, ctx->d_pyr, ctx->d_sel, ctx->d_selcount, ctx->d_momw, d_records, so);
+        else
+            hipLaunchKernelGGL(describe_kernel<15>, dim3((g.cap + 4 * kKpw - 1) / (4 * kKpw), n_frames), dim3(256), 0,
+                               S(stream), g, ctx->d_pyr, ctx->d_sel, ctx->d_selcount, ctx->d_momw, d_records, so);
+    } else {
+        const int tiles_x = (g.W + kDTile - 1) / kDTile, tiles_y = (g.H + kDTile - 1) / kDTile;
+        if (g.angle_in_radians)
+            hipLaunchKernelGGL(describe_tile_kernel<19>, dim3(tiles_x * tiles_y, n_frames), dim3(256), 0, S(stream), g,
+                               ctx->d_pyr, ctx->d_cellkey, ctx->d_cellslot, ctx->d_momw_tile, tiles_x, d_records, so);
+        else
+            hipLaunchKernelGGL(describe_tile_kernel<15>, dim3(tiles_x * tiles_y, n_frames), dim3(256), 0, S(stream), g,
+                               ctx->d_pyr, ctx->d_cellkey, ctx->d_cellslot, ctx->d_momw_tile, tiles_x, d_records, so);
+    }
     CTX_LAUNCH_CHECK(ctx, "describe_batch");
     return ORBFE_OK;
 }

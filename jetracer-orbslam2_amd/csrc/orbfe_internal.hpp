@@ -185,6 +185,9 @@ struct orbfe_ctx {
     uint32_t *d_cellkey = nullptr;  // [max_batch][K]
     uint4 *d_sel = nullptr;         // [max_batch][cap] selected keypoints in cell order: {cell, x | y << 16, key, 0}
     int32_t *d_selcount = nullptr;  // [max_batch]
+    uint16_t *d_cellslot = nullptr; // [max_batch][K] record slot of each cell's keypoint, 0xFFFF = not selected
+    uint4 *d_momw_tile = nullptr;   // describe (tile form): int8 weight fragments of the moment MFMAs
+    bool describe_patch = false;    // ORBFE_DESCRIBE=patch: the per-keypoint-patch kernel (A/B timing)
     uint8_t *d_mdesc = nullptr;     // [max_batch][cap][32]  matcher scratch: dense descriptors
     uint8_t *d_mpos = nullptr;      // [max_batch][cap] float2 matcher scratch: positions
     uint4 *d_mexp = nullptr;        // [max_batch][cap_pad][8]  MFMA matcher: descriptors as e2m1 fragments (cap <= 16384)

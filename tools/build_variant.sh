@@ -1,0 +1,17 @@
+#!/bin/bash
+# build a variant of liborbfe.so with extra flags / defines into jetracer-orbslam2_amd/.variants/<name>/liborbfe.so
+# usage: tools/build_variant.sh <name> [extra hipcc flags...]   (ORBFE_LIB=<that path> selects it for A/B timing)
+set -e
+NAME=$1; shift
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+SRC=$ROOT/jetracer-orbslam2_amd/csrc
+OUT=$ROOT/jetracer-orbslam2_amd/.variants/$NAME
+mkdir -p $OUT
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function"
+/opt/rocm/bin/hipcc $F "$@" -c -o $OUT/stage.o $SRC/stage_kernels.hip &
+/opt/rocm/bin/hipcc $F "$@" -c -o $OUT/batch.o $SRC/batch_kernels.hip &
+/opt/rocm/bin/hipcc $F -fno-honor-nans -mllvm -amdgpu-mfma-vgpr-form "$@" -c -o $OUT/mfma.o $SRC/match_mfma.hip &
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/liborbfe.so $OUT/stage.o $OUT/batch.o $OUT/mfma.o
+rm -f $OUT/*.o
+echo $OUT/liborbfe.so
