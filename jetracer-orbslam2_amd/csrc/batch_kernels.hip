@@ -947,7 +947,9 @@ constexpr int kDTile = 64;
 template <int R>
 struct TileGeom {
     static constexpr int kHaloX = (R + 15) / 16 * 16;                 // 16 (R = 15) / 32 (R = 19): chunk-aligned
-    static constexpr int kPitch = kDTile + 2 * kHaloX;                // 96 / 128 bytes
+    // + one spare chunk per row: 96 / 128 bytes put rows 4 (or all!) apart on the same LDS banks; with 112 /
+    // 144 the row stride is 28 / 36 dwords and the descriptor's byte gathers spread over twice the banks
+    static constexpr int kPitch = kDTile + 2 * kHaloX + 16;           // 112 / 144 bytes
     static constexpr int kRows = kDTile + 2 * R;                      // 94 / 102
     static constexpr int kChunksRow = kPitch / 16;
     static constexpr int kChunks = kRows * kChunksRow;                // 564 / 816
@@ -1053,24 +1055,30 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
     const int nkp = s_nkp;
     if (nkp == 0) return; // uniform
     // ---- border tiles: zero what the moments exclude / what lies outside the image
+    // ---- border tiles: zero what the moments exclude / what lies outside the image: rows gy <= 0 and
+    //      gy >= H, columns gx <= 0 and gx >= W (only the strips concerned are touched)
     if (ox <= 0 || ox + P > g.W || oy <= 0 || oy + G::kRows > g.H) { // uniform
         uint32_t *t32 = reinterpret_cast<uint32_t *>(s_tile);
-        for (int i = tid; i < G::kBytes / 4; i += 256) {
-            const int r = i / (P / 4), c4 = i - r * (P / 4);
-            const int gy = oy + r, gx = ox + 4 * c4;
+        constexpr int PD = P / 4;
+        const int rtop = oy <= 0 ? 1 - oy : 0;                           // rows [0, rtop) lie at gy <= 0
+        const int rbot = g.H - oy < G::kRows ? g.H - oy : G::kRows;      // rows [rbot, kRows) at gy >= H
+        for (int i = tid; i < rtop * PD; i += 256) t32[i] = 0u;
+        for (int i = rbot * PD + tid; i < G::kRows * PD; i += 256) t32[i] = 0u;
+        // column strips of the rows in between: `lanes` threads per row, one dword each per pass
+        auto strip = [&](int d0, int nd, int first_keep, int last_keep) { // dwords [d0, d0 + nd); bytes outside [first_keep, last_keep) go
+            const int sh = nd <= 8 ? 3 : 5, d = d0 + (tid & ((1 << sh) - 1));
+            if (d >= d0 + nd) return;
             uint32_t keep = 0xFFFFFFFFu;
-            if (gy <= 0 || gy >= g.H) keep = 0u;
+            const int lo = first_keep - 4 * d, hi = last_keep - 4 * d; // byte j of this dword kept iff lo <= j < hi
+            if (lo >= 4 || hi <= 0) keep = 0u;
             else {
-                // byte j is kept iff 0 < gx + j < W
-                int lo = 1 - gx, hi = g.W - gx; // j in [lo, hi)
-                lo = lo < 0 ? 0 : (lo > 4 ? 4 : lo);
-                hi = hi < 0 ? 0 : (hi > 4 ? 4 : hi);
-                const uint32_t mlo = lo >= 4 ? 0u : (0xFFFFFFFFu << (8 * lo));
-                const uint32_t mhi = hi >= 4 ? 0xFFFFFFFFu : ((1u << (8 * hi)) - 1u);
-                keep = hi > lo ? (mlo & mhi) : 0u;
+                if (lo > 0) keep &= 0xFFFFFFFFu << (8 * lo);
+                if (hi < 4) keep &= (1u << (8 * hi)) - 1u;
             }
-            if (keep != 0xFFFFFFFFu) t32[i] = keep ? (t32[i] & keep) : 0u;
-        }
+            for (int r = rtop + (tid >> sh); r < rbot; r += 256 >> sh) t32[r * PD + d] &= keep;
+        };
+        if (ox <= 0) strip(0, (1 - ox + 3) / 4, 1 - ox, P);              // gx <= 0  <=> byte < 1 - ox
+        if (ox + P > g.W) strip((g.W - ox) / 4, PD - (g.W - ox) / 4, 0, g.W - ox); // gx >= W <=> byte >= W - ox
         __syncthreads();
     }
     // weight fragments of the moment MFMAs and this lane's four rBRIEF pattern rows
@@ -1080,24 +1088,33 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
     float4 pat[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) pat[r] = reinterpret_cast<const float4 *>(c_pattern_f)[64 * r + lane];
-    const uint32_t tile_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t *)s_tile;
 
     // ---- phase A: moments of groups of kKpw keypoints on the matrix cores -> s_m10 / s_m01
     for (int grp = wv; grp * kKpw < nkp; grp += 4) { // uniform
         const int k0 = grp * kKpw;
         const int nk = nkp - k0 < kKpw ? nkp - k0 : kKpw;
         // A fragment of lane (chunk c, row = keypoint + 4 * slice) = 16 bytes of disc-box row
-        // 8 ks + 2 slice + (c >> 1), columns 16 (c & 1) .. + 15, read at the keypoint's own byte
-        // position (a misaligned ds_read_b128, which gfx950 serves)
+        // 8 ks + 2 slice + (c >> 1), columns 16 (c & 1) .. + 15, at the keypoint's own byte position
         const int row = lane & 15, c = lane >> 4;
         const int j = k0 + ((row & 3) < nk ? (row & 3) : nk - 1);
         const uint32_t xy = s_kxy[j];
         const int kb = ((int)(xy >> 16) - 15 - oy) * P + (int)(xy & 0xFFFFu) - 15 - ox;
-        const uint32_t aaddr = tile_lds + (uint32_t)(kb + (2 * (row >> 2) + (c >> 1)) * P + 16 * (c & 1));
+        // 16 bytes from an arbitrary byte address = 5 aligned dwords realigned by v_alignbyte: byte-misaligned
+        // wide LDS reads are served one lane at a time on gfx950 (26.8 ns per wave-instruction against < 3 ns
+        // aligned, tools/lds_unaligned_rate.hip)
+        const int abyte = kb + (2 * (row >> 2) + (c >> 1)) * P + 16 * (c & 1);
+        const uint32_t *a32 = reinterpret_cast<const uint32_t *>(s_tile + (abyte & ~3));
+        const uint32_t ash = (uint32_t)abyte & 3u;
         u32x4 av[G::kMom];
 #pragma unroll
-        for (int ks = 0; ks < G::kMom; ks++) // the waits are per read (in-flight registers never leave an asm block)
-            asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(av[ks]) : "v"(aaddr), "n"(ks * 8 * P) : "memory");
+        for (int ks = 0; ks < G::kMom; ks++) {
+            const uint32_t *q = a32 + ks * 2 * P; // 8 rows further
+            const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+            av[ks].x = __builtin_amdgcn_alignbyte(d1, d0, ash);
+            av[ks].y = __builtin_amdgcn_alignbyte(d2, d1, ash);
+            av[ks].z = __builtin_amdgcn_alignbyte(d3, d2, ash);
+            av[ks].w = __builtin_amdgcn_alignbyte(d4, d3, ash);
+        }
         v4i acc = {0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < G::kMom; ks++) {
