@@ -137,6 +137,18 @@ int orbfe_match_keypoints(const float *d_pos_prev, const uint32_t *d_descriptors
                           int32_t *d_match_idx, int32_t *d_num_matched,
                           orbfe_stream_t stream);
 
+/* The compacted outputs kernel_match_keypoints writes for every matched prev keypoint
+ * (src/cuda/post_processing.cu:176-198): previous_matched_points / current_matched_points (double3)
+ * and d_pos_frame = uint16 x | uint16 y of the matched CURRENT keypoint, which match_keypoints then
+ * copies into slam_frame_t::keypoints_x / keypoints_y (:300-331, src/SlamGpuPipeline/types.h:29-30).
+ * d_match_idx is orbfe_match_keypoints' output.  The lists are written in ascending prev index
+ * (the reference's atomicAdd slots come in arbitrary order) and *d_num_matched receives their
+ * length.  The point arrays are optional (RGB-D only): pass d_points_* and d_*_matched NULL together. */
+int orbfe_match_compact(const int32_t *d_match_idx, int keypoints_num_prev, const double *d_points_prev,
+                        const double *d_points_curr, const float *d_pos_curr, double *d_prev_matched,
+                        double *d_curr_matched, uint16_t *d_keypoints_x, uint16_t *d_keypoints_y,
+                        int32_t *d_num_matched, orbfe_stream_t stream);
+
 /* rs2_intrinsics (librealsense2 rs_types.h) as the reference's kernels read it
  * (src/cuda/cuda-align.cu:57-112): same field order and meaning. */
 typedef struct orbfe_intrinsics {
@@ -160,6 +172,15 @@ int orbfe_keypoint_pixel_to_point(const uint32_t *d_aligned_depth, const orbfe_i
                                   uint32_t *d_descriptors_out, const uint32_t *d_descriptors_in,
                                   int keypoints_num, int32_t *d_valid_keypoints_num,
                                   int fix_depth_index, orbfe_stream_t stream);
+
+/* kernel_reproject_prev_points, src/cuda/post_processing.cu:72-90 (with project_point_to_pixel_double,
+ * :11-43): the prev frame's 3-D points moved by T_w2c_prev_curr (HOST pointer to 16 doubles,
+ * column-major as Eigen::Matrix4d) and projected to pixels -- the positions orbfe_match_keypoints takes
+ * as d_pos_prev.  Models 0 (none) and 1 (modified Brown-Conrady) as in the reference; 2 and 3
+ * (it asserts / never uses them): ORBFE_ERR_UNSUPPORTED.  Parity unpinned at the ulp level (Eigen's
+ * product order and nvcc's FMA contraction are not observable): ((T_i0 x + T_i1 y) + T_i2 z) + T_i3. */
+int orbfe_reproject_points(float *d_pos_out, const double *d_points_prev, int keypoints_num_prev,
+                           const double *T_w2c_prev_curr, const orbfe_intrinsics *intrin, orbfe_stream_t stream);
 
 /* EXT: brute-force 256-bit Hamming matcher.  For every descriptor i of A the
  * lexicographic minimum (distance, index) over B; window < 0 disables the position gate

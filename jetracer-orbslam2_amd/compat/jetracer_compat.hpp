@@ -15,6 +15,8 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <memory>
 #include <vector>
 
 #include "../../include/orbfe.h"
@@ -131,6 +133,118 @@ inline void match_keypoints(const float2 *d_pos_prev_reprojected, const uint32_t
                                         d_descriptors_curr, keypoints_num_curr, max_pixel_distance,
                                         max_hamming_distance, d_match_idx, d_keypoints_num_matched,
                                         detail::S(stream)), "match_keypoints");
+}
+
+// ---- slam_frame_t and the reference's match_keypoints host function -------------------------------
+// src/SlamGpuPipeline/types.h:25-65: the same fields with the same names and types, minus what this path
+// does not own (the rgbd_frame handle) and with Eigen::Matrix4d as its 16 column-major doubles
+// (Eigen::Matrix4d::data() is exactly that).  Buffers are released as the reference's destructor does.
+static_assert(sizeof(double3) == 24, "double3 is three packed doubles, as in CUDA");
+
+typedef struct slam_frame {
+    unsigned char *image = nullptr;
+    size_t image_length = 0;
+    uint16_t *keypoints_x = nullptr; // matched current keypoints, filled by match_keypoints (post_processing.cu:300-331)
+    uint16_t *keypoints_y = nullptr;
+    std::shared_ptr<double[]> h_points;
+    std::shared_ptr<uint32_t[]> h_descriptors;
+
+    float2 *d_pos = nullptr;       // compacted valid keypoints (cuda-align.cu:282-364 / orbfe_keypoint_pixel_to_point)
+    double *d_points = nullptr;    // their 3-D points, 3 doubles each
+    uint32_t *d_descriptors = nullptr;
+
+    int keypoints_count = 0;
+    int h_valid_keypoints_num = 0;
+    int h_matched_keypoints_num = 0;
+    float3 theta = {0.f, 0.f, 0.f};
+
+    double T_c2w[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    double T_w2c[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+
+    ~slam_frame()
+    {
+        if (image) free(image);
+        if (keypoints_x) free(keypoints_x);
+        if (keypoints_y) free(keypoints_y);
+        if (d_pos) (void)hipFree(d_pos);
+        if (d_points) (void)hipFree(d_points);
+        if (d_descriptors) (void)hipFree(d_descriptors);
+    }
+} slam_frame_t;
+
+namespace detail {
+inline void hip_check(hipError_t e, const char *what)
+{
+    if (e != hipSuccess) {
+        std::fprintf(stderr, "orbfe: %s failed: %s\n", what, hipGetErrorString(e));
+        std::exit(EXIT_FAILURE);
+    }
+}
+} // namespace detail
+
+// src/cuda/post_processing.cuh:40-51 / post_processing.cu:234-341, argument for argument:
+//   Eigen::Matrix4d T_w2c_prev_curr  -> its 16 doubles (T.data());
+//   const rs2_intrinsics *d_rgb_intrin -> the same struct on the HOST (orbfe_intrinsics has rs2_intrinsics'
+//     layout; the library passes it to the kernel by value);
+//   d_valid_keypoints_num (a device int the reference's kernel dereferences) is unused: the count is
+//     current_frame->h_valid_keypoints_num.
+// Same observable results: h_*_matched_points, *h_keypoints_num_matched, current_frame->keypoints_x / _y
+// (malloc'ed here, freed by ~slam_frame), in prev-keypoint order instead of atomic order.  Like the
+// reference it allocates scratch and synchronises the stream; the C ABI underneath does neither.
+inline void match_keypoints(std::shared_ptr<slam_frame_t> current_frame, std::shared_ptr<slam_frame_t> previous_frame,
+                            int max_pixel_distance, int max_hamming_distance, const double *T_w2c_prev_curr,
+                            int * /*d_valid_keypoints_num*/, int *d_keypoints_num_matched, int *h_keypoints_num_matched,
+                            double3 *h_current_matched_points, double3 *h_previous_matched_points,
+                            const orbfe_intrinsics *h_rgb_intrin, hipStream_t stream)
+{
+    const int n_prev = previous_frame->h_valid_keypoints_num, n_curr = current_frame->h_valid_keypoints_num;
+    const int cap = previous_frame->keypoints_count > n_prev ? previous_frame->keypoints_count : n_prev;
+    float2 *d_pos_tmp = nullptr;
+    int32_t *d_match_idx = nullptr;
+    uint16_t *d_pos_frame = nullptr;
+    double3 *d_prev_m = nullptr, *d_curr_m = nullptr;
+    const size_t n = (size_t)(cap > 0 ? cap : 1);
+    detail::hip_check(hipMalloc((void **)&d_pos_tmp, sizeof(float2) * n), "hipMalloc");
+    detail::hip_check(hipMalloc((void **)&d_match_idx, sizeof(int32_t) * n), "hipMalloc");
+    detail::hip_check(hipMalloc((void **)&d_pos_frame, sizeof(uint16_t) * n * 2), "hipMalloc");
+    detail::hip_check(hipMalloc((void **)&d_prev_m, sizeof(double3) * n), "hipMalloc");
+    detail::hip_check(hipMalloc((void **)&d_curr_m, sizeof(double3) * n), "hipMalloc");
+    detail::check(orbfe_reproject_points(reinterpret_cast<float *>(d_pos_tmp), previous_frame->d_points, n_prev,
+                                         T_w2c_prev_curr, h_rgb_intrin, detail::S(stream)), "reproject_points");
+    detail::check(orbfe_match_keypoints(reinterpret_cast<const float *>(d_pos_tmp), previous_frame->d_descriptors, n_prev,
+                                        reinterpret_cast<const float *>(current_frame->d_pos),
+                                        current_frame->d_descriptors, n_curr, max_pixel_distance, max_hamming_distance,
+                                        d_match_idx, d_keypoints_num_matched, detail::S(stream)), "match_keypoints");
+    detail::check(orbfe_match_compact(d_match_idx, n_prev, previous_frame->d_points, current_frame->d_points,
+                                      reinterpret_cast<const float *>(current_frame->d_pos),
+                                      reinterpret_cast<double *>(d_prev_m), reinterpret_cast<double *>(d_curr_m),
+                                      d_pos_frame, d_pos_frame + n, d_keypoints_num_matched, detail::S(stream)),
+                  "match_compact");
+    detail::hip_check(hipMemcpyAsync(h_keypoints_num_matched, d_keypoints_num_matched, sizeof(int), hipMemcpyDeviceToHost,
+                                     stream), "hipMemcpyAsync");
+    detail::hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize"); // the reference syncs here too (:315)
+    const size_t m = (size_t)*h_keypoints_num_matched;
+    if (h_previous_matched_points)
+        detail::hip_check(hipMemcpyAsync(h_previous_matched_points, d_prev_m, sizeof(double3) * m, hipMemcpyDeviceToHost,
+                                         stream), "hipMemcpyAsync");
+    if (h_current_matched_points)
+        detail::hip_check(hipMemcpyAsync(h_current_matched_points, d_curr_m, sizeof(double3) * m, hipMemcpyDeviceToHost,
+                                         stream), "hipMemcpyAsync");
+    if (current_frame->keypoints_x) free(current_frame->keypoints_x);
+    if (current_frame->keypoints_y) free(current_frame->keypoints_y);
+    current_frame->keypoints_x = (uint16_t *)malloc(sizeof(uint16_t) * (m ? m : 1));
+    current_frame->keypoints_y = (uint16_t *)malloc(sizeof(uint16_t) * (m ? m : 1));
+    detail::hip_check(hipMemcpyAsync(current_frame->keypoints_x, d_pos_frame, sizeof(uint16_t) * m, hipMemcpyDeviceToHost,
+                                     stream), "hipMemcpyAsync");
+    detail::hip_check(hipMemcpyAsync(current_frame->keypoints_y, d_pos_frame + n, sizeof(uint16_t) * m,
+                                     hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
+    detail::hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    current_frame->h_matched_keypoints_num = (int)m;
+    (void)hipFree(d_pos_tmp);
+    (void)hipFree(d_match_idx);
+    (void)hipFree(d_pos_frame);
+    (void)hipFree(d_prev_m);
+    (void)hipFree(d_curr_m);
 }
 
 } // namespace Jetracer

@@ -290,6 +290,81 @@ keypoint_pixel_to_point_kernel(const uint32_t *__restrict__ depth_img, orbfe_int
 }
 
 // ------------------------------------------------------------------------------------
+// a11 / a12  the compacted outputs of kernel_match_keypoints (post_processing.cu:176-198): matched
+// prev / curr 3-D points (double3) and the matched curr positions as uint16 x / y (the frame's
+// keypoints_x / keypoints_y, :300-331).  One workgroup walks the prev keypoints in chunks of 256
+// with a running offset, so the lists are in prev order (the reference's atomics give any order).
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+match_compact_kernel(const int32_t *__restrict__ match_idx, int n_prev, const double *__restrict__ points_prev,
+                     const double *__restrict__ points_curr, const float *__restrict__ pos_curr,
+                     double *__restrict__ prev_matched, double *__restrict__ curr_matched,
+                     uint16_t *__restrict__ kx, uint16_t *__restrict__ ky, int32_t *__restrict__ n_matched)
+{
+    __shared__ int s_wave[4];
+    int base = 0;
+    for (int i0 = 0; i0 < n_prev; i0 += 256) {
+        const int idx = i0 + threadIdx.x;
+        const int pair = idx < n_prev ? match_idx[idx] : -1;
+        const bool ok = pair >= 0;
+        int total;
+        const int slot = base + block_excl_scan(ok, s_wave, &total);
+        if (ok) {
+            if (points_prev && prev_matched) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) prev_matched[3 * (size_t)slot + k] = points_prev[3 * (size_t)idx + k];
+            }
+            if (points_curr && curr_matched) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) curr_matched[3 * (size_t)slot + k] = points_curr[3 * (size_t)pair + k];
+            }
+            kx[slot] = (uint16_t)pos_curr[2 * (size_t)pair];
+            ky[slot] = (uint16_t)pos_curr[2 * (size_t)pair + 1];
+        }
+        base += total;
+    }
+    if (threadIdx.x == 0 && n_matched) *n_matched = base;
+}
+
+// f4 (part)  kernel_reproject_prev_points + project_point_to_pixel_double (post_processing.cu:11-43, :72-90)
+struct Mat4 {
+    double m[16]; // column-major, as Eigen::Matrix4d stores it
+};
+__global__ void reproject_points_kernel(float *__restrict__ pos_out, const double *__restrict__ points, int n, Mat4 T,
+                                        orbfe_intrinsics K)
+{
+    ORBFE_NO_CONTRACT
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const double px = points[3 * (size_t)idx], py = points[3 * (size_t)idx + 1], pz = points[3 * (size_t)idx + 2];
+    double e[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        double t = T.m[i] * px + T.m[4 + i] * py;
+        t = t + T.m[8 + i] * pz;
+        t = t + T.m[12 + i];
+        e[i] = t;
+    }
+    float x = (float)(e[0] / e[2]), y = (float)(e[1] / e[2]);
+    if (K.model == 1) {
+        const float r2 = x * x + y * y;
+        float f = 1 + K.coeffs[0] * r2;
+        f = f + K.coeffs[1] * r2 * r2;
+        f = f + K.coeffs[4] * r2 * r2 * r2;
+        x *= f;
+        y *= f;
+        float dx = x + 2 * K.coeffs[2] * x * y;
+        dx = dx + K.coeffs[3] * (r2 + 2 * x * x);
+        float dy = y + 2 * K.coeffs[3] * x * y;
+        dy = dy + K.coeffs[2] * (r2 + 2 * y * y);
+        x = dx;
+        y = dy;
+    }
+    pos_out[2 * (size_t)idx] = x * K.fx + K.ppx;
+    pos_out[2 * (size_t)idx + 1] = y * K.fy + K.ppy;
+}
+
+// ------------------------------------------------------------------------------------
 // a11  reference matcher (post_processing.cu:92-200).  Thread i = prev keypoint i; its
 // "tid" in the reference's 32-thread block is i & 31.  Curr keypoints are staged in LDS in
 // tiles of 32; inside a tile of m entries thread tid visits j = (s + tid) % m, s = 0..m-1,
@@ -586,6 +661,38 @@ int orbfe_match_keypoints(const float *d_pos_prev, const uint32_t *d_desc_prev, 
                        d_pos_prev, d_desc_prev, n_prev, d_pos_curr, d_desc_curr, n_curr,
                        (float)max_px, max_ham, d_match_idx, d_num_matched);
     return launch_status("match_keypoints");
+}
+
+int orbfe_match_compact(const int32_t *d_match_idx, int n_prev, const double *d_points_prev,
+                        const double *d_points_curr, const float *d_pos_curr, double *d_prev_matched,
+                        double *d_curr_matched, uint16_t *d_keypoints_x, uint16_t *d_keypoints_y,
+                        int32_t *d_num_matched, orbfe_stream_t stream)
+{
+    ARG_CHECK(n_prev >= 0 && d_num_matched);
+    ARG_CHECK(n_prev == 0 || (d_match_idx && d_pos_curr && d_keypoints_x && d_keypoints_y));
+    ARG_CHECK((d_points_prev == nullptr) == (d_prev_matched == nullptr));
+    ARG_CHECK((d_points_curr == nullptr) == (d_curr_matched == nullptr));
+    hipLaunchKernelGGL(match_compact_kernel, dim3(1), dim3(256), 0, S(stream), d_match_idx, n_prev, d_points_prev,
+                       d_points_curr, d_pos_curr, d_prev_matched, d_curr_matched, d_keypoints_x, d_keypoints_y,
+                       d_num_matched);
+    return launch_status("match_compact");
+}
+
+int orbfe_reproject_points(float *d_pos_out, const double *d_points_prev, int n, const double *T_w2c_prev_curr,
+                           const orbfe_intrinsics *intrin, orbfe_stream_t stream)
+{
+    ARG_CHECK(n >= 0 && T_w2c_prev_curr && intrin);
+    if (intrin->model == 2 || intrin->model == 3) { // the reference asserts / needs atan + tan: not on its live path
+        set_thread_error("reproject_points: cannot project to an inverse-distorted or f-theta image (model %d)", intrin->model);
+        return ORBFE_ERR_UNSUPPORTED;
+    }
+    if (n == 0) return ORBFE_OK;
+    ARG_CHECK(d_pos_out && d_points_prev);
+    Mat4 T;
+    memcpy(T.m, T_w2c_prev_curr, sizeof(T.m));
+    hipLaunchKernelGGL(reproject_points_kernel, dim3((n + 255) / 256), dim3(256), 0, S(stream), d_pos_out, d_points_prev,
+                       n, T, *intrin);
+    return launch_status("reproject_points");
 }
 
 int orbfe_keypoint_pixel_to_point(const uint32_t *d_aligned_depth, const orbfe_intrinsics *intrin, int image_width,

@@ -80,6 +80,10 @@ _SIGS = {
     "orbfe_keypoint_pixel_to_point": (C.c_int, [C.c_void_p, C.POINTER(Intrinsics), C.c_int, C.c_int, C.c_void_p,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "orbfe_match_compact": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "orbfe_reproject_points": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(Intrinsics),
+                                         C.c_void_p]),
     "orbfe_match256": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                  C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "orbfe_default_config": (None, [C.POINTER(Config), C.c_int, C.c_int]),

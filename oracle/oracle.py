@@ -214,6 +214,33 @@ def match_keypoints(pos_prev, desc_prev, pos_curr, desc_curr, max_px=2, max_ham=
     return idx[:n_prev], n
 
 
+def match_compact(match_idx, pos_curr, points_prev=None, points_curr=None):
+    """-> (keypoints_x u16[n], keypoints_y u16[n], prev_matched f64[n,3] | None, curr_matched | None)"""
+    match_idx = np.ascontiguousarray(match_idx, dtype=np.int32)
+    pos_curr = np.ascontiguousarray(pos_curr, dtype=np.float32).reshape(-1, 2)
+    n_prev = len(match_idx)
+    kx = np.zeros(max(n_prev, 1), np.uint16)
+    ky = np.zeros(max(n_prev, 1), np.uint16)
+    pm = cm = None
+    if points_prev is not None:
+        points_prev = np.ascontiguousarray(points_prev, dtype=np.float64).reshape(-1, 3)
+        points_curr = np.ascontiguousarray(points_curr, dtype=np.float64).reshape(-1, 3)
+        pm = np.zeros((max(n_prev, 1), 3))
+        cm = np.zeros((max(n_prev, 1), 3))
+    n = lib().oracle_match_compact(_p(match_idx), n_prev, _p(points_prev), _p(points_curr), _p(pos_curr), _p(pm), _p(cm),
+                                   _p(kx), _p(ky))
+    return kx[:n], ky[:n], (pm[:n] if pm is not None else None), (cm[:n] if cm is not None else None)
+
+
+def reproject_points(points_prev, T, intrin):
+    """points_prev f64[n,3], T 4x4 (row-major numpy, converted to Eigen's column-major), intrin = Intrinsics"""
+    points_prev = np.ascontiguousarray(points_prev, dtype=np.float64).reshape(-1, 3)
+    Tc = np.ascontiguousarray(np.asarray(T, dtype=np.float64).T).reshape(-1)  # column-major
+    out = np.zeros((max(len(points_prev), 1), 2), np.float32)
+    lib().oracle_reproject_points(_p(out), _p(points_prev), len(points_prev), _p(Tc), C.byref(intrin))
+    return out[:len(points_prev)]
+
+
 def match256(desc_a, desc_b, pos_a=None, pos_b=None, window=-1, max_dist=256):
     desc_a = np.ascontiguousarray(desc_a, dtype=np.uint8).reshape(-1, 32)
     desc_b = np.ascontiguousarray(desc_b, dtype=np.uint8).reshape(-1, 32)

@@ -531,6 +531,79 @@ int oracle_match_keypoints(const float *pos_prev, const uint32_t *desc_prev, int
 }
 
 /* ------------------------------------------------------------------------------------
+ * a11 / a12 output contract of kernel_match_keypoints    src/cuda/post_processing.cu:176-198
+ * A matched prev keypoint idx with partner pair_idx appends
+ *     previous_matched_points[slot] = previous_points[idx]            (double3)
+ *     current_matched_points[slot]  = current_points[pair_idx]        (double3)
+ *     d_pos_frame[slot]             = uint16_t(d_pos[pair_idx].x)
+ *     d_pos_frame[keypoints_num + slot] = uint16_t(d_pos[pair_idx].y)
+ * where slot comes from two atomicAdds (arbitrary order).  Decision: slots are taken in ascending
+ * prev index.  The two halves of d_pos_frame are the frame's keypoints_x / keypoints_y
+ * (post_processing.cu:300-331, types.h:29-30).  Points may be NULL (RGB-D only).  Returns the count.
+ * ------------------------------------------------------------------------------------ */
+int oracle_match_compact(const int32_t *match_idx, int n_prev, const double *points_prev,
+                         const double *points_curr, const float *pos_curr, double *prev_matched,
+                         double *curr_matched, uint16_t *keypoints_x, uint16_t *keypoints_y)
+{
+    int slot = 0;
+    for (int idx = 0; idx < n_prev; idx++) {
+        const int pair_idx = match_idx[idx];
+        if (pair_idx < 0) continue;
+        if (points_prev && prev_matched)
+            for (int k = 0; k < 3; k++) prev_matched[3 * slot + k] = points_prev[3 * idx + k];
+        if (points_curr && curr_matched)
+            for (int k = 0; k < 3; k++) curr_matched[3 * slot + k] = points_curr[3 * pair_idx + k];
+        keypoints_x[slot] = (uint16_t)pos_curr[2 * pair_idx];
+        keypoints_y[slot] = (uint16_t)pos_curr[2 * pair_idx + 1];
+        slot++;
+    }
+    return slot;
+}
+
+/* ------------------------------------------------------------------------------------
+ * f4 (part)  kernel_reproject_prev_points + project_point_to_pixel_double
+ *            src/cuda/post_processing.cu:11-43, :72-90
+ * e = T * (x, y, z, 1) in double (T column-major as Eigen::Matrix4d stores it), then the
+ * librealsense projection in FLOAT: x = e0 / e2, y = e1 / e2 (double quotients narrowed),
+ * optional modified-Brown-Conrady / f-theta distortion, pixel = x * fx + ppx.
+ * PARITY UNPINNED at the ulp level: Eigen's product order and nvcc's FMA contraction are not
+ * observable here; decided as ((T_i0 x + T_i1 y) + T_i2 z) + T_i3, no contraction, and the float
+ * polynomial evaluated left to right as written.
+ * ------------------------------------------------------------------------------------ */
+void oracle_reproject_points(float *pos_out, const double *points_prev, int n, const double *T,
+                             const oracle_intrinsics *intrin)
+{
+    ORBFE_NO_CONTRACT
+    for (int idx = 0; idx < n; idx++) {
+        const double px = points_prev[3 * idx], py = points_prev[3 * idx + 1], pz = points_prev[3 * idx + 2];
+        double e[3];
+        for (int i = 0; i < 3; i++) {
+            double t = T[i] * px + T[4 + i] * py;
+            t = t + T[8 + i] * pz;
+            t = t + T[12 + i];
+            e[i] = t;
+        }
+        float x = (float)(e[0] / e[2]), y = (float)(e[1] / e[2]);
+        if (intrin->model == 1) { /* RS2_DISTORTION_MODIFIED_BROWN_CONRADY */
+            const float r2 = x * x + y * y;
+            float f = 1 + intrin->coeffs[0] * r2;
+            f = f + intrin->coeffs[1] * r2 * r2;
+            f = f + intrin->coeffs[4] * r2 * r2 * r2;
+            x *= f;
+            y *= f;
+            float dx = x + 2 * intrin->coeffs[2] * x * y;
+            dx = dx + intrin->coeffs[3] * (r2 + 2 * x * x);
+            float dy = y + 2 * intrin->coeffs[3] * x * y;
+            dy = dy + intrin->coeffs[2] * (r2 + 2 * y * y);
+            x = dx;
+            y = dy;
+        }
+        pos_out[2 * idx] = x * intrin->fx + intrin->ppx;
+        pos_out[2 * idx + 1] = y * intrin->fy + intrin->ppy;
+    }
+}
+
+/* ------------------------------------------------------------------------------------
  * f2  kernel_keypoint_pixel_to_point    src/cuda/cuda-align.cu:282-364
  *     deproject_pixel_to_point_double   src/cuda/cuda-align.cu:85-112
  * Keep keypoints with depth > 1 and score > 1.0f; deproject in double.  The pixel offsets

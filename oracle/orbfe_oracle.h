@@ -85,6 +85,13 @@ int oracle_keypoint_pixel_to_point(const uint32_t *aligned_depth, const oracle_i
 int oracle_match_keypoints(const float *pos_prev, const uint32_t *desc_prev, int n_prev,
                            const float *pos_curr, const uint32_t *desc_curr, int n_curr,
                            int max_px, int max_ham, int32_t *match_idx /*[n_prev], -1 = none*/);
+/* a11/a12: the compacted lists kernel_match_keypoints writes (post_processing.cu:176-198), in prev order */
+int oracle_match_compact(const int32_t *match_idx, int n_prev, const double *points_prev,
+                         const double *points_curr, const float *pos_curr, double *prev_matched,
+                         double *curr_matched, uint16_t *keypoints_x, uint16_t *keypoints_y);
+/* f4 (part): kernel_reproject_prev_points, post_processing.cu:11-43, :72-90; T column-major 4x4 */
+void oracle_reproject_points(float *pos_out, const double *points_prev, int n, const double *T,
+                             const oracle_intrinsics *intrin);
 /* EXT C.9: brute-force 256-bit; (dist, idx) lexicographic minimum; window < 0 = none */
 void oracle_match256(const uint8_t *descA, const float *posA, int nA, const uint8_t *descB,
                      const float *posB, int nB, int window, int max_dist, int32_t *idx,

@@ -26,7 +26,9 @@ def gpu():
     import torch
     import orbfe
     assert torch.cuda.is_available(), "GPU tests need a HIP device"
-    if not os.path.exists(orbfe.LIB_PATH) or not os.path.exists(os.path.join(ROOT, "examples", "buildstream_port")):
+    built = [orbfe.LIB_PATH, os.path.join(ROOT, "jetracer-orbslam2_amd", "liborbfe_dist.so"),
+             os.path.join(ROOT, "examples", "buildstream_port"), os.path.join(ROOT, "examples", "match_port")]
+    if not all(os.path.exists(b) for b in built):
         import __graft_entry__  # clean checkout: build the HIP library, the oracle and the example
         __graft_entry__.build()
     orbfe.lib()  # raises if liborbfe.so is not built

@@ -211,3 +211,114 @@ def test_calls_leave_the_current_device_alone(gpu):
     cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
     ctx.extract(buf.data_ptr(), 64, 64 * 64, 1, rec.data_ptr(), cnt.data_ptr(), None, stream(torch))
     assert hip.hipGetDevice(ctypes.byref(cur)) == 0 and cur.value == torch.cuda.current_device()
+
+
+# ------------------------------------------------------------------ a11 / a12 output contract
+@pytest.mark.parametrize("n_prev,n_curr,with_points", [(0, 5, True), (7, 0, True), (300, 300, True), (405, 380, False),
+                                                        (1000, 900, True), (5000, 4000, False)])
+def test_match_compact(gpu, oracle_mod, n_prev, n_curr, with_points):
+    """previous_matched_points / current_matched_points / d_pos_frame of kernel_match_keypoints
+    (post_processing.cu:176-198), in prev order."""
+    torch, orbfe = gpu
+    rng = np.random.default_rng(n_prev * 7 + n_curr)
+    idx = np.where(rng.random(n_prev) < 0.6, rng.integers(0, max(n_curr, 1), n_prev), -1).astype(np.int32)
+    if n_curr == 0:
+        idx[:] = -1
+    pos_curr = (rng.random((max(n_curr, 1), 2)) * [847, 479]).astype(np.float32)
+    pts_prev = rng.normal(size=(max(n_prev, 1), 3)) * 1000
+    pts_curr = rng.normal(size=(max(n_curr, 1), 3)) * 1000
+    d_idx, d_pos = dev(torch, idx if n_prev else np.zeros(1, np.int32)), dev(torch, pos_curr)
+    d_pp, d_pc = dev(torch, pts_prev), dev(torch, pts_curr)
+    m = max(n_prev, 1)
+    kx = torch.full((m,), 0xEEEE - 65536, dtype=torch.int16, device="cuda")
+    ky = torch.full((m,), 0xEEEE - 65536, dtype=torch.int16, device="cuda")
+    pm = torch.full((m, 3), -7.0, dtype=torch.float64, device="cuda")
+    cm = torch.full((m, 3), -7.0, dtype=torch.float64, device="cuda")
+    cnt = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+    orbfe.check(orbfe.lib().orbfe_match_compact(d_idx.data_ptr(), n_prev, d_pp.data_ptr() if with_points else None,
+                                                d_pc.data_ptr() if with_points else None, d_pos.data_ptr(),
+                                                pm.data_ptr() if with_points else None,
+                                                cm.data_ptr() if with_points else None, kx.data_ptr(), ky.data_ptr(),
+                                                cnt.data_ptr(), stream(torch)))
+    rkx, rky, rpm, rcm = oracle_mod.match_compact(idx[:n_prev], pos_curr, pts_prev if with_points else None,
+                                                  pts_curr if with_points else None)
+    n = int(cnt.cpu()[0])
+    assert n == len(rkx) == int((idx[:n_prev] >= 0).sum())
+    np.testing.assert_array_equal(kx.cpu().numpy().view(np.uint16)[:n], rkx)
+    np.testing.assert_array_equal(ky.cpu().numpy().view(np.uint16)[:n], rky)
+    assert (kx.cpu().numpy().view(np.uint16)[n:] == 0xEEEE).all()
+    if with_points:
+        np.testing.assert_array_equal(pm.cpu().numpy()[:n].view(np.uint64), rpm.view(np.uint64))
+        np.testing.assert_array_equal(cm.cpu().numpy()[:n].view(np.uint64), rcm.view(np.uint64))
+        assert (pm.cpu().numpy()[n:] == -7.0).all()
+    # an unbalanced pointer pair is an argument error
+    assert orbfe.lib().orbfe_match_compact(d_idx.data_ptr(), n_prev, d_pp.data_ptr(), None, d_pos.data_ptr(), None, None,
+                                           kx.data_ptr(), ky.data_ptr(), cnt.data_ptr(), stream(torch)) == orbfe.ERR_INVALID_ARG
+
+
+@pytest.mark.parametrize("model", [0, 1])
+def test_reproject_points(gpu, oracle_mod, model):
+    """kernel_reproject_prev_points (post_processing.cu:72-90): pose * point, then the float projection."""
+    torch, orbfe = gpu
+    rng = np.random.default_rng(5 + model)
+    n = 777
+    pts = np.stack([rng.normal(size=n) * 400, rng.normal(size=n) * 300, rng.uniform(300, 5000, n)], 1)
+    a = 0.03
+    T = np.array([[np.cos(a), 0, np.sin(a), 12.5], [0, 1, 0, -3.25], [-np.sin(a), 0, np.cos(a), 40.0], [0, 0, 0, 1]])
+    coeffs = (0.0, 0.0, 0.0, 0.0, 0.0) if model == 0 else (0.11, -0.23, 0.0007, -0.0004, 0.09)
+    intr = orbfe.Intrinsics(848, 480, 421.5, 237.25, 615.5, 615.25, model, (C.c_float * 5)(*coeffs))
+    ointr = oracle_mod.Intrinsics(848, 480, 421.5, 237.25, 615.5, 615.25, model, (C.c_float * 5)(*coeffs))
+    d_pts = dev(torch, pts)
+    out = torch.full((n, 2), -1.0, dtype=torch.float32, device="cuda")
+    Tc = (C.c_double * 16)(*np.ascontiguousarray(T.T).reshape(-1))  # column-major, as Eigen stores it
+    orbfe.check(orbfe.lib().orbfe_reproject_points(out.data_ptr(), d_pts.data_ptr(), n, Tc, C.byref(intr), stream(torch)))
+    ref = oracle_mod.reproject_points(pts, T, ointr)
+    np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    assert np.isfinite(ref).all() and ref[:, 0].std() > 10
+    intr.model = 2
+    assert orbfe.lib().orbfe_reproject_points(out.data_ptr(), d_pts.data_ptr(), n, Tc, C.byref(intr),
+                                              stream(torch)) == orbfe.ERR_UNSUPPORTED
+
+
+def test_cpp_match_port(gpu, oracle_mod, tmp_path):
+    """examples/match_port.cpp: two frames through the reference's call sequence incl.
+    keypoint_pixel_to_point and match_keypoints(current, previous, 2, 4, T, ...) with slam_frame_t
+    (buildStream.cpp:399-556) via compat/jetracer_compat.hpp; outputs must equal the oracle's."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "match_port")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    w, h = 848, 480
+    a, b = synth.shifted_pair(w, h, 77, dx=1, dy=0, **synth.DENSE)
+    rgbs = [np.stack([g, g, g], -1) for g in (a, b)]
+    rng = np.random.default_rng(3)
+    depth = rng.integers(0, 4000, size=(h, w)).astype(np.uint32)
+    depth[rng.random((h, w)) < 0.2] = 0
+    paths = [str(tmp_path / n) for n in ("a.bin", "b.bin", "depth.bin", "out.bin")]
+    rgbs[0].tofile(paths[0]); rgbs[1].tofile(paths[1]); depth.tofile(paths[2])
+    subprocess.check_call([exe, str(w), str(h), *paths])
+    raw = np.fromfile(paths[3], np.uint8)
+    nprev, ncurr, n = raw[:12].view(np.int32)
+    kx = raw[12:12 + 2 * n].view(np.uint16)
+    ky = raw[12 + 2 * n:12 + 4 * n].view(np.uint16)
+    pm = raw[12 + 4 * n:12 + 4 * n + 24 * n].view(np.float64).reshape(n, 3)
+    cm = raw[12 + 28 * n:12 + 52 * n].view(np.float64).reshape(n, 3)
+    # the oracle, call by call
+    intr = oracle_mod.Intrinsics(w, h, w * 0.5 - 3.25, h * 0.5 + 1.5, 615.5, 615.25, 0, (C.c_float * 5)(0, 0, 0, 0, 0))
+    frames = []
+    for rgb in rgbs:
+        gray = oracle_mod.rgb_to_grayscale(rgb)
+        ref = oracle_mod.extract_frame(gray, oracle_mod.make_config(w, h, levels=1))
+        pos, pts, d32, _ = oracle_mod.keypoint_pixel_to_point(depth, intr, ref["pos"], ref["score"], ref["desc32"], 0)
+        frames.append((pos, pts, d32))
+    (ppos, ppts, pd32), (cpos, cpts, cd32) = frames
+    assert (nprev, ncurr) == (len(ppos), len(cpos))
+    pos_tmp = oracle_mod.reproject_points(ppts, np.eye(4), intr)
+    ridx, rn = oracle_mod.match_keypoints(pos_tmp, pd32, cpos, cd32, 2, 4)
+    rkx, rky, rpm, rcm = oracle_mod.match_compact(ridx, cpos, ppts, cpts)
+    assert n == rn == len(rkx) and n > 20
+    np.testing.assert_array_equal(kx, rkx)
+    np.testing.assert_array_equal(ky, rky)
+    np.testing.assert_array_equal(pm.view(np.uint64), rpm.view(np.uint64))
+    np.testing.assert_array_equal(cm.view(np.uint64), rcm.view(np.uint64))
