@@ -325,9 +325,20 @@ __device__ inline int fast_score_packed(const uint8_t *p, uint32_t t2, int arc)
     return rb > rd ? rb : rd;
 }
 
+// STAGE = the stage API's orbfe_detect (one frame, caller-owned pitched levels): the tile is found from the
+// per-level tile counts instead of the context's tile list, and the tile's scores are also written to
+// the caller's f32 response maps (the reference's detect leaves them filled, fast.cu:292-407).
+struct StageTiles {
+    int first[8 + 1];  // first tile of level l; first[n_levels] = number of tiles
+    int tiles_x[8];
+    float *resp[8];    // response map of level l (may be null) ...
+    int resp_pitch[8]; // ... and its pitch in floats
+};
+
+template <bool STAGE>
 __global__ void __launch_bounds__(256)
 detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc *__restrict__ tiles,
-                   uint32_t *__restrict__ cellkey, int tile_first, int tile_step)
+                   uint32_t *__restrict__ cellkey, int tile_first, int tile_step, StageTiles st)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_px32[kPxH * kPxDw];
     __shared__ __attribute__((aligned(16))) uint16_t s_sc[kScH * kScPitch];
@@ -344,7 +355,16 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
 
     int f, tile_id;
     xcd_remap(gridDim.x, gridDim.y, &f, &tile_id);
-    const TileDesc td = tiles[tile_first + tile_id * tile_step]; // shard: every tile_step-th tile
+    TileDesc td;
+    if (STAGE) {
+        int lvl = 0;
+#pragma unroll
+        for (int i = 1; i < 8; i++) lvl += (i < g.Ld && tile_id >= st.first[i]) ? 1 : 0;
+        const int t = tile_id - st.first[lvl], tyy = t / st.tiles_x[lvl];
+        td = TileDesc{(int16_t)lvl, (int16_t)(t - tyy * st.tiles_x[lvl]), (int16_t)tyy, 0};
+    } else {
+        td = tiles[tile_first + tile_id * tile_step]; // shard: every tile_step-th tile
+    }
     const int l = td.level;
     const int W = g.lv[l].w, H = g.lv[l].h, P = g.lv[l].pitch;
     const uint8_t *img = pyr + (size_t)f * g.frame_stride + g.lv[l].offset;
@@ -502,6 +522,16 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
         n2 += (int)__popcll(m);
     }
     __syncthreads(); // every wave's scores are in s_sc
+
+    if (STAGE && st.resp[l]) { // the tile's part of the caller's response map, zeros included
+        float *rp = st.resp[l];
+        const int rpitch = st.resp_pitch[l];
+        for (int i = tid; i < kTileW * kTileH; i += 256) {
+            const int ry = i / kTileW, rx = i - ry * kTileW;
+            if (x0 + rx < W && y0 + ry < H)
+                rp[(size_t)(y0 + ry) * rpitch + x0 + rx] = (float)s_sc[(ry + 1) * kScPitch + rx + 1];
+        }
+    }
 
     // ---- D: strict 3x3 maximum on the positives, then the cell's maximum key
     for (int i = lane; i < n2; i += 64) {
@@ -1396,6 +1426,67 @@ match_batch_256_kernel(const Desc8 *__restrict__ mdesc, const float2 *__restrict
     }
 }
 
+// Stage API: cell keys (left in the caller's d_score buffer, 4 bytes per cell) -> the reference's feature
+// grid: score as float in place, position, level (nms.cu:246-252; empty cells: 0, (0,0), 0 -- Q5)
+__global__ void stage_decode_kernel(int K, int cells_x, int cell0, float *__restrict__ score_and_key,
+                                    float *__restrict__ d_pos, int *__restrict__ d_level)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const uint32_t key = __float_as_uint(score_and_key[k]);
+    int s, l, x, y;
+    nms_decode(key, k % cells_x, k / cells_x, cell0, &s, &l, &x, &y);
+    score_and_key[k] = (float)s;
+    d_pos[2 * k] = (float)x;
+    d_pos[2 * k + 1] = (float)y;
+    d_level[k] = l;
+}
+
+int launch_detect_stage(const orbfe_pyramid_level *lv, int n_levels, int threshold, int arc, float *d_pos, float *d_score,
+                        int *d_level, hipStream_t stream)
+{
+    DeviceGeom g;
+    memset(&g, 0, sizeof(g));
+    g.W = (int)lv[0].image_width;
+    g.H = (int)lv[0].image_height;
+    g.L = g.Ld = n_levels;
+    g.cell = 32; // CELL_SIZE_WIDTH / HEIGHT, src/SlamGpuPipeline/defines.h:17-18
+    g.cells_x = (g.W + 31) / 32;
+    g.cells_y = (g.H + 31) / 32;
+    g.K = g.cells_x * g.cells_y;
+    g.cap = g.K;
+    g.threshold = threshold;
+    g.arc = arc;
+    StageTiles st;
+    memset(&st, 0, sizeof(st));
+    int n_tiles = 0;
+    for (int l = 0; l < n_levels; l++) {
+        g.lv[l].w = (int)lv[l].image_width;
+        g.lv[l].h = (int)lv[l].image_height;
+        g.lv[l].pitch = (int)lv[l].image_pitch;
+        g.lv[l].offset = (size_t)(reinterpret_cast<uintptr_t>(lv[l].image) - reinterpret_cast<uintptr_t>(lv[0].image)); // modulo 2^64
+        st.first[l] = n_tiles;
+        st.tiles_x[l] = (g.lv[l].w + kTileW - 1) / kTileW;
+        st.resp[l] = lv[l].response;
+        st.resp_pitch[l] = (int)(lv[l].response_pitch / sizeof(float));
+        if (g.lv[l].w >= 7 && g.lv[l].h >= 7) // else no pixel is >= 3 from every border: the map is all zero
+            n_tiles += st.tiles_x[l] * ((g.lv[l].h + kTileH - 1) / kTileH);
+        else if (lv[l].response && g.lv[l].w > 0 && g.lv[l].h > 0 &&
+                 hipMemset2DAsync(lv[l].response, lv[l].response_pitch, 0, (size_t)g.lv[l].w * sizeof(float), g.lv[l].h,
+                                  stream) != hipSuccess)
+            return ORBFE_ERR_HIP;
+    }
+    for (int l = n_levels; l <= 8; l++) st.first[l] = n_tiles;
+    uint32_t *keys = reinterpret_cast<uint32_t *>(d_score); // 4 bytes per cell: the key, then (decode) the score
+    if (hipMemsetAsync(keys, 0, (size_t)g.K * sizeof(uint32_t), stream) != hipSuccess) return ORBFE_ERR_HIP;
+    if (n_tiles > 0)
+        hipLaunchKernelGGL(detect_tile_kernel<true>, dim3(n_tiles, 1), dim3(256), 0, stream, g, lv[0].image, nullptr, keys,
+                           0, 1, st);
+    hipLaunchKernelGGL(stage_decode_kernel, dim3((g.K + 255) / 256), dim3(256), 0, stream, g.K, g.cells_x, g.cell, d_score,
+                       d_pos, d_level);
+    return hipGetLastError() == hipSuccess ? ORBFE_OK : ORBFE_ERR_HIP;
+}
+
 } // namespace orbfe
 
 // ======================================================================================
@@ -1673,8 +1764,8 @@ int orbfe_detect_batch_shard(orbfe_ctx *ctx, int n_frames, int shard_index, int 
     // levels and of busy / empty image regions)
     const int n_mine = ctx->n_tiles > shard_index ? (ctx->n_tiles - shard_index + shard_count - 1) / shard_count : 0;
     if (n_mine > 0)
-        hipLaunchKernelGGL(detect_tile_kernel, dim3(n_mine, n_frames), dim3(256), 0, S(stream), g, ctx->d_pyr,
-                           ctx->d_tiles, ctx->d_cellkey, shard_index, shard_count);
+        hipLaunchKernelGGL(detect_tile_kernel<false>, dim3(n_mine, n_frames), dim3(256), 0, S(stream), g, ctx->d_pyr,
+                           ctx->d_tiles, ctx->d_cellkey, shard_index, shard_count, StageTiles{});
     CTX_LAUNCH_CHECK(ctx, "detect_batch");
     return ORBFE_OK;
 }

@@ -152,6 +152,11 @@ void launch_match_mfma(const orbfe_keypoint *d_records, const int32_t *d_counts,
                        int stride, int cap, int capP, int max_dist, uint4 *mexp, float *mkey, int32_t *d_idx,
                        int32_t *d_dist, hipStream_t stream);
 
+// batch_kernels.hip: orbfe_detect of the stage API on the fused tile kernel (one launch for all levels,
+// scores also written to the caller's response maps); integer threshold, arc 9..12, dword-aligned levels
+int launch_detect_stage(const orbfe_pyramid_level *lv, int n_levels, int threshold, int arc, float *d_pos, float *d_score,
+                        int *d_level, hipStream_t stream);
+
 // a per-frame count read from a caller's device buffer, made safe to index with: a stale or corrupt
 // count must not walk past the frame's cap records
 __host__ __device__ inline int clamp_count(int n, int cap)

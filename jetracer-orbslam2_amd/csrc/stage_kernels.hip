@@ -7,9 +7,39 @@
 #include "orbfe_internal.hpp"
 #include "device_common.hpp"
 
+#include <mutex>
+
 namespace orbfe {
 
 static thread_local char t_err[512];
+
+// Which arc length a LUT buffer was built for (orbfe_fast_calculate_lut remembers the last 16 buffers):
+// orbfe_detect takes the reference's opaque LUT pointer, but its fused path tests arcs in closed form
+// and needs the number.  An unknown pointer (a table the caller filled some other way) takes the
+// unfused path, which reads the table itself.
+static std::mutex g_lut_mutex;
+static struct { const void *ptr; int arc; } g_lut_arcs[16];
+static int g_lut_next = 0;
+
+static void remember_lut(const void *ptr, int arc)
+{
+    std::lock_guard<std::mutex> lock(g_lut_mutex);
+    for (auto &e : g_lut_arcs)
+        if (e.ptr == ptr) {
+            e.arc = arc;
+            return;
+        }
+    g_lut_arcs[g_lut_next] = {ptr, arc};
+    g_lut_next = (g_lut_next + 1) % 16;
+}
+
+static int lut_arc(const void *ptr)
+{
+    std::lock_guard<std::mutex> lock(g_lut_mutex);
+    for (auto &e : g_lut_arcs)
+        if (e.ptr == ptr) return e.arc;
+    return 0;
+}
 
 void set_thread_error(const char *fmt, ...)
 {
@@ -150,7 +180,10 @@ __global__ void grid_nms_kernel(NmsLevels lv, int cell0, int cells_x, int K,
     const int cell = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (cell >= K) return; // whole wave
     const int cx = cell % cells_x, cy = cell / cells_x;
-    uint32_t best = 0;
+    // Responses are floats here (any float threshold, fast.cuh:28-40: with t = 7.5 they are x.5), so the
+    // key is 64 bits: the response's bit pattern (positive floats order like unsigned integers) above
+    // the level / tie-rank field of nms_key().  Its unsigned maximum is the reference's winner.
+    uint64_t best = 0;
     for (int l = 0; l < lv.n; l++) {
         const int c = cell0 >> l;
         if (c == 0) break;
@@ -165,19 +198,21 @@ __global__ void grid_nms_kernel(NmsLevels lv, int cell0, int cells_x, int K,
             const bool is_max = v > q[-P] && v > q[-P + 1] && v > q[1] && v > q[P + 1] &&
                                 v > q[P] && v > q[P - 1] && v > q[-1] && v > q[-P - 1];
             if (!is_max) continue;
-            const uint32_t key = nms_key((int)v, l, x, y, cell0);
+            const uint64_t key = ((uint64_t)__float_as_uint(v) << 32) | nms_key(0, l, x, y, cell0);
             best = key > best ? key : best;
         }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)best, off);
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)best, off), hi = (uint32_t)__shfl_xor((int)(uint32_t)(best >> 32), off);
+        const uint64_t o = ((uint64_t)hi << 32) | lo;
         best = o > best ? o : best;
     }
     if (lane == 0) {
-        int s, l, x, y;
-        nms_decode(best, cx, cy, cell0, &s, &l, &x, &y);
-        d_score[cell] = (float)s;
+        int s = 0, l = 0, x = 0, y = 0;
+        // position and level from the low field (a non-zero score field makes nms_decode treat the cell as taken)
+        if (best) nms_decode((1u << 15) | (uint32_t)(best & 0x7FFFu), cx, cy, cell0, &s, &l, &x, &y);
+        d_score[cell] = __uint_as_float((uint32_t)(best >> 32));
         d_pos[2 * cell] = (float)x;
         d_pos[2 * cell + 1] = (float)y;
         d_level[cell] = l;
@@ -561,6 +596,7 @@ int orbfe_fast_calculate_lut(unsigned char *d_lut, int min_arc, orbfe_stream_t s
 {
     ARG_CHECK(d_lut && min_arc >= 1 && min_arc <= 16);
     hipLaunchKernelGGL(fast_lut_kernel, dim3(256), dim3(256), 0, S(stream), d_lut, min_arc);
+    remember_lut(d_lut, min_arc);
     return launch_status("fast_calculate_lut");
 }
 
@@ -611,7 +647,26 @@ int orbfe_detect(const orbfe_pyramid_level *lv, int n_levels, const unsigned cha
                  float threshold, float *d_pos, float *d_score, int *d_level,
                  orbfe_stream_t stream)
 {
-    ARG_CHECK(lv && n_levels >= 1);
+    ARG_CHECK(lv && n_levels >= 1 && d_lut && d_pos && d_score && d_level);
+    if (n_levels > 6) { // 32 >> 6 == 0: the reference divides by zero (nms.cu:273), Q12
+        set_thread_error("detect: at most 6 levels with 32-pixel cells");
+        return ORBFE_ERR_UNSUPPORTED;
+    }
+    // Fused path: FAST score + 3x3 NMS + cell maximum of every level in ONE launch (the batch path's tile
+    // kernel), the scores also written to the caller's response maps; needs what that kernel assumes.
+    const int arc = lut_arc(d_lut);
+    bool fused = arc >= 9 && arc <= 12 && threshold >= 1.0f && threshold <= 254.0f && threshold == (float)(int)threshold;
+    for (int i = 0; i < n_levels && fused; i++) {
+        ARG_CHECK(lv[i].image && lv[i].image_pitch >= lv[i].image_width);
+        ARG_CHECK(!lv[i].response || lv[i].response_pitch >= lv[i].image_width * sizeof(float));
+        fused = lv[i].image_pitch % 4 == 0 && (reinterpret_cast<uintptr_t>(lv[i].image) & 3u) == 0 &&
+                lv[i].image_pitch < (1u << 24) && lv[i].image_width > 0 && lv[i].image_height > 0;
+    }
+    if (fused) {
+        const int rc = launch_detect_stage(lv, n_levels, (int)threshold, arc, d_pos, d_score, d_level, S(stream));
+        if (rc != ORBFE_OK) set_thread_error("detect: launch failed");
+        return rc;
+    }
     for (int i = 0; i < n_levels; i++) {
         int rc = orbfe_fast_calc_corner_response(
             (int)lv[i].image_width, (int)lv[i].image_height, (int)lv[i].image_pitch, lv[i].image, 3,

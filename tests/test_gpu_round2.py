@@ -322,3 +322,63 @@ def test_cpp_match_port(gpu, oracle_mod, tmp_path):
     np.testing.assert_array_equal(ky, rky)
     np.testing.assert_array_equal(pm.view(np.uint64), rpm.view(np.uint64))
     np.testing.assert_array_equal(cm.view(np.uint64), rcm.view(np.uint64))
+
+
+# ------------------------------------------------------------------ stage API detect: fused path, float thresholds
+def _detect_case(torch, orbfe, oracle_mod, w, h, levels, arc, thr, build_lut_on_device, pitch_extra, with_resp=True, seed=9):
+    from test_gpu_parity import bits, pitched
+    lut = oracle_mod.fast_lut(arc)
+    imgs = [oracle_mod.gaussian_blur_3x3(synth.frame(w, h, seed, "rects", **synth.DENSE))]
+    for _ in range(1, levels):
+        imgs.append(oracle_mod.halfsample(imgs[-1]))
+    resps = [oracle_mod.fast_response(i, lut, thr) if min(i.shape) > 0 else np.zeros(i.shape, np.float32) for i in imgs]
+    rpos, rscore, rlevel = oracle_mod.grid_nms(resps, 32)
+    k = oracle_mod.num_cells(w, h)
+    pitch = [((w >> l) + 3) // 4 * 4 + pitch_extra for l in range(levels)]  # a multiple of 4 iff pitch_extra is
+    d_img = [pitched(torch, imgs[l], pitch[l]) for l in range(levels)]
+    d_res = [torch.full((max(h >> l, 1), (w >> l) + 5), -1.0, dtype=torch.float32, device="cuda") for l in range(levels)]
+    lv = orbfe.make_levels([(d_img[l].data_ptr(), w >> l, h >> l, pitch[l]) for l in range(levels)],
+                           [(d_res[l].data_ptr() if with_resp else 0, w >> l, h >> l, ((w >> l) + 5) * 4) for l in range(levels)])
+    if build_lut_on_device:
+        d_lut = torch.zeros(65536, dtype=torch.uint8, device="cuda")
+        orbfe.check(orbfe.lib().orbfe_fast_calculate_lut(d_lut.data_ptr(), arc, stream(torch)))
+    else:
+        d_lut = dev(torch, lut)
+    grid = torch.full((4 * k,), -3.0, dtype=torch.float32, device="cuda")
+    b = grid.data_ptr()
+    orbfe.check(orbfe.lib().orbfe_detect(lv, levels, d_lut.data_ptr(), thr, b, b + 8 * k, b + 12 * k, stream(torch)))
+    g = grid.cpu().numpy()
+    np.testing.assert_array_equal(bits(g[2 * k:3 * k]), bits(rscore))
+    np.testing.assert_array_equal(bits(g[:2 * k].reshape(k, 2)), bits(rpos))
+    np.testing.assert_array_equal(g[3 * k:].view(np.int32), rlevel)
+    if with_resp:
+        for l in range(levels):
+            got = d_res[l].cpu().numpy()
+            np.testing.assert_array_equal(bits(got[:h >> l, :w >> l]), bits(resps[l]), err_msg="response level %d" % l)
+            assert (got[:, w >> l:] == -1.0).all(), "response written outside the level width"
+    return int((rscore > 0).sum())
+
+
+@pytest.mark.parametrize("w,h,levels,arc,thr,extra", [
+    (640, 480, 1, 12, 13.0, 0),    # the reference's live configuration (PYRAMID_LEVELS 1)
+    (640, 480, 6, 12, 13.0, 0),
+    (848, 480, 6, 9, 13.0, 4),     # odd level widths from level 4 on, padded pitch
+    (100, 70, 5, 10, 20.0, 8),     # levels 4 is 6x4: no tiles, response zeroed by memset
+    (1280, 720, 4, 11, 5.0, 0),
+])
+def test_detect_stage_fused_path(gpu, oracle_mod, w, h, levels, arc, thr, extra):
+    """LUT built by orbfe_fast_calculate_lut + integer threshold + dword-aligned levels: orbfe_detect runs the
+    fused tile kernel (one launch) and must leave the same feature grid AND response maps as the oracle."""
+    torch, orbfe = gpu
+    n = _detect_case(torch, orbfe, oracle_mod, w, h, levels, arc, thr, True, extra)
+    assert n > 10
+    _detect_case(torch, orbfe, oracle_mod, w, h, levels, arc, thr, True, extra, with_resp=False)
+
+
+@pytest.mark.parametrize("thr,on_device,extra", [(7.5, True, 0), (13.0, False, 0), (13.0, True, 3), (0.5, True, 0)])
+def test_detect_stage_float_threshold_and_unaligned(gpu, oracle_mod, thr, on_device, extra):
+    """Non-integer thresholds (responses x.5), foreign LUT buffers and odd pitches take the unfused path;
+    grid_nms must then compare float responses (it truncated them)."""
+    torch, orbfe = gpu
+    n = _detect_case(torch, orbfe, oracle_mod, 640, 480, 5, 12, thr, on_device, extra)
+    assert n > 10
