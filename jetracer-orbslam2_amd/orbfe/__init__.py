@@ -121,6 +121,27 @@ _SIGS = {
 
 EXPORTS = tuple(_SIGS)  # every symbol include/orbfe.h declares
 
+
+class FrameMessage(C.Structure):  # orbfe_frame_message, include/orbfe_wire.h
+    _fields_ = [("theta", C.c_float * 3), ("width", C.c_int32), ("height", C.c_int32), ("channels", C.c_int32),
+                ("keypoints_x", C.c_void_p), ("keypoints_y", C.c_void_p), ("matched_keypoints", C.c_int32),
+                ("image", C.c_void_p), ("image_length", C.c_size_t)]
+
+
+_WIRE_SIGS = {  # include/orbfe_wire.h: the result record's wire format (host code inside liborbfe.so)
+    "orbfe_bson_new": (C.c_void_p, []),
+    "orbfe_bson_free": (None, [C.c_void_p]),
+    "orbfe_bson_add": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t]),
+    "orbfe_bson_process": (C.c_int, [C.c_void_p]),
+    "orbfe_bson_ptr": (C.c_void_p, [C.c_void_p]),
+    "orbfe_bson_size": (C.c_uint32, [C.c_void_p]),
+    "orbfe_wire_angles": (None, [C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
+    "orbfe_wire_frame_size": (C.c_size_t, [C.POINTER(FrameMessage)]),
+    "orbfe_wire_frame_encode": (C.c_int, [C.POINTER(FrameMessage), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "orbfe_bson_find": (C.c_int, [C.c_void_p, C.c_size_t, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+}
+WIRE_EXPORTS = tuple(_WIRE_SIGS)
+
 _lib = None
 
 
@@ -134,7 +155,7 @@ def lib():
                                  "`make -C jetracer-orbslam2_amd/csrc` (needs hipcc; there is "
                                  "no CPU fallback)" % LIB_PATH)
         L = C.CDLL(LIB_PATH)
-        for name, (res, args) in _SIGS.items():
+        for name, (res, args) in list(_SIGS.items()) + list(_WIRE_SIGS.items()):
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
