@@ -1487,6 +1487,114 @@ int launch_detect_stage(const orbfe_pyramid_level *lv, int n_levels, int thresho
     return hipGetLastError() == hipSuccess ? ORBFE_OK : ORBFE_ERR_HIP;
 }
 
+// ------------------------------------------------------------------------------------
+// 256-bit matching inside a position window: an index instead of brute force.  A query only has to look
+// at the candidates whose position lies within +-window pixels, i.e. in the few grid cells around it, so
+// the curr frame's records are bucketed by cell (counting sort, one workgroup per frame) and a query walks
+// one contiguous range of the sorted list per cell row of its window: ~10 candidates instead of all 2000
+// at the bench's C3 shape (stereo pairs, +-16 px).  The result is the same lexicographic minimum
+// (distance, index) over the candidates inside the window as the brute-force form (oracle_match256).
+// ------------------------------------------------------------------------------------
+__device__ inline int bucket_coord(float v, float inv_cell, int n)
+{
+    // floor(v / cell) clamped to [0, n - 1]; monotone in v, so |a - b| <= w implies
+    // bucket(a - w) <= bucket(b) <= bucket(a + w).  fmaxf / fminf also absorb a NaN.
+    return (int)fminf(fmaxf(floorf(v * inv_cell), 0.0f), (float)(n - 1));
+}
+
+// bend[b] = END of bucket b in `sorted` (= start of bucket b + 1); one workgroup per curr frame
+__global__ void __launch_bounds__(256)
+match_bucket_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *__restrict__ counts, int cap, int first,
+                    int stride, int K, int cells_x, int cells_y, float inv_cell, int32_t *__restrict__ bend_all,
+                    uint16_t *__restrict__ sorted_all)
+{
+    __shared__ int s_wave[4];
+    __shared__ int s_carry;
+    const int f = first + blockIdx.x * stride + 1; // the pair's curr frame
+    const int n = clamp_count(counts[f], cap);
+    const uint32_t *R = reinterpret_cast<const uint32_t *>(records + (size_t)f * cap);
+    int32_t *bend = bend_all + (size_t)f * K;
+    uint16_t *sorted = sorted_all + (size_t)f * cap;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int k = tid; k < K; k += 256) bend[k] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int b = bucket_coord(__uint_as_float(R[13 * (size_t)i + 1]), inv_cell, cells_y) * cells_x +
+                      bucket_coord(__uint_as_float(R[13 * (size_t)i]), inv_cell, cells_x);
+        atomicAdd(&bend[b], 1);
+    }
+    __syncthreads();
+    // exclusive prefix sum over the K counts, 256 buckets per pass with a running carry
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < K; base += 256) {
+        const int k = base + tid;
+        // (the counts were made by L2 atomics: read them past this CU's L1)
+        const int c = k < K ? __hip_atomic_load(&bend[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        const int incl = wave_incl_scan_i32(c);
+        if (lane == 63) s_wave[wv] = incl;
+        __syncthreads();
+        int off = s_carry;
+        for (int u = 0; u < wv; u++) off += s_wave[u];
+        if (k < K) bend[k] = off + incl - c; // start of bucket k
+        __syncthreads();
+        if (tid == 255) s_carry = off + incl;
+        __syncthreads();
+    }
+    // scatter: the atomic cursor turns every start into the bucket's end
+    for (int i = tid; i < n; i += 256) {
+        const int b = bucket_coord(__uint_as_float(R[13 * (size_t)i + 1]), inv_cell, cells_y) * cells_x +
+                      bucket_coord(__uint_as_float(R[13 * (size_t)i]), inv_cell, cells_x);
+        sorted[atomicAdd(&bend[b], 1)] = (uint16_t)i;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+match_window_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *__restrict__ counts, int cap, int first,
+                    int stride, int K, int cells_x, int cells_y, float inv_cell, const int32_t *__restrict__ bend_all,
+                    const uint16_t *__restrict__ sorted_all, int window, int max_dist, int32_t *__restrict__ out_idx,
+                    int32_t *__restrict__ out_dist)
+{
+    int pk, blk;
+    xcd_remap(gridDim.x, gridDim.y, &pk, &blk); // all query blocks of a pair share one L2
+    const int p = first + pk * stride;
+    const int nA = clamp_count(counts[p], cap), nB = clamp_count(counts[p + 1], cap);
+    const int i = blk * 256 + threadIdx.x;
+    if (i >= cap) return;
+    uint32_t best = 0xFFFFFFFFu;
+    if (i < nA && nB > 0) {
+        const uint32_t *A = reinterpret_cast<const uint32_t *>(records + (size_t)p * cap) + 13 * (size_t)i;
+        const uint32_t *B = reinterpret_cast<const uint32_t *>(records + (size_t)(p + 1) * cap);
+        const int32_t *bend = bend_all + (size_t)(p + 1) * K;
+        const uint16_t *sorted = sorted_all + (size_t)(p + 1) * cap;
+        const float ax = __uint_as_float(A[0]), ay = __uint_as_float(A[1]), win = (float)window;
+        uint32_t a[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) a[k] = A[5 + k];
+        const int bx0 = bucket_coord(ax - win, inv_cell, cells_x), bx1 = bucket_coord(ax + win, inv_cell, cells_x);
+        const int by0 = bucket_coord(ay - win, inv_cell, cells_y), by1 = bucket_coord(ay + win, inv_cell, cells_y);
+        for (int by = by0; by <= by1; by++) {
+            const int g0 = by * cells_x + bx0, g1 = by * cells_x + bx1;
+            int t = g0 > 0 ? bend[g0 - 1] : 0;
+            const int e = bend[g1];
+            for (; t < e; t++) {
+                const uint32_t j = sorted[t];
+                const uint32_t *r = B + 13 * (size_t)j;
+                if (fabsf(ax - __uint_as_float(r[0])) > win || fabsf(ay - __uint_as_float(r[1])) > win) continue;
+                uint32_t dist = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) dist += __popc(a[k] ^ r[5 + k]);
+                const uint32_t key = (dist << 16) | j;
+                best = key < best ? key : best;
+            }
+        }
+    }
+    const int bd = (int)(best >> 16), bj = (int)(best & 0xFFFFu);
+    const bool ok = best != 0xFFFFFFFFu && bd <= max_dist;
+    out_idx[(size_t)pk * cap + i] = ok ? bj : -1;
+    if (out_dist) out_dist[(size_t)pk * cap + i] = ok ? bd : -1;
+}
+
 } // namespace orbfe
 
 // ======================================================================================
@@ -1615,6 +1723,10 @@ int orbfe_create(const orbfe_config *cfg, orbfe_ctx **out)
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_cellslot, B * g.K * sizeof(uint16_t));
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_mdesc, B * g.cap * 32);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_mpos, B * g.cap * 8);
+    if (g.cap <= 65535) { // windowed 256-bit matching: cell buckets of the curr frames
+        if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_bend, B * g.K * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_bsorted, B * g.cap * sizeof(uint16_t));
+    }
     ctx->cap_pad = (g.cap + 15) / 16 * 16;
     {
         const std::vector<int8_t> w = make_moment_weights(g.angle_in_radians ? 19 : 15);
@@ -1656,6 +1768,8 @@ void orbfe_destroy(orbfe_ctx *ctx)
     if (ctx->d_tiles) (void)hipFree(ctx->d_tiles);
     if (ctx->d_mdesc) (void)hipFree(ctx->d_mdesc);
     if (ctx->d_mpos) (void)hipFree(ctx->d_mpos);
+    if (ctx->d_bend) (void)hipFree(ctx->d_bend);
+    if (ctx->d_bsorted) (void)hipFree(ctx->d_bsorted);
     if (ctx->d_mexp) (void)hipFree(ctx->d_mexp);
     if (ctx->d_mkey) (void)hipFree(ctx->d_mkey);
     if (ctx->d_momw) (void)hipFree(ctx->d_momw);
@@ -1887,6 +2001,19 @@ int orbfe_match_pairs(orbfe_ctx *ctx, const orbfe_keypoint *d_records, const int
             const int capP = ctx->cap_pad;
             launch_match_mfma(d_records, d_counts, n_frames, n_pairs, first, stride, cap, capP, max_distance, ctx->d_mexp,
                               ctx->d_mkey, d_idx, d_dist, S(stream));
+            CTX_LAUNCH_CHECK(ctx, "match");
+            return ORBFE_OK;
+        }
+        const DeviceGeom &g = ctx->g;
+        // a window that spans few cells: walk the cell index (a few candidates per query) instead of all pairs
+        const int wc = window >= 0 ? 2 * ((window + g.cell - 1) / g.cell) + 1 : 0; // cells per window edge, at most
+        if (window >= 0 && ctx->d_bend && (long long)wc * wc * 4 <= (long long)g.K) {
+            const float inv_cell = 1.0f / (float)g.cell; // exact: the cell is a power of two
+            hipLaunchKernelGGL(match_bucket_kernel, dim3(n_pairs), block, 0, S(stream), d_records, d_counts, cap, first,
+                               stride, g.K, g.cells_x, g.cells_y, inv_cell, ctx->d_bend, ctx->d_bsorted);
+            hipLaunchKernelGGL(match_window_kernel, grid, block, 0, S(stream), d_records, d_counts, cap, first, stride, g.K,
+                               g.cells_x, g.cells_y, inv_cell, ctx->d_bend, ctx->d_bsorted, window, max_distance, d_idx,
+                               d_dist);
             CTX_LAUNCH_CHECK(ctx, "match");
             return ORBFE_OK;
         }

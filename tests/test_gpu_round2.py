@@ -382,3 +382,46 @@ def test_detect_stage_float_threshold_and_unaligned(gpu, oracle_mod, thr, on_dev
     torch, orbfe = gpu
     n = _detect_case(torch, orbfe, oracle_mod, 640, 480, 5, 12, thr, on_device, extra)
     assert n > 10
+
+
+# ------------------------------------------------------------------ windowed 256-bit matching through the cell index
+@pytest.mark.parametrize("w,h,cell,window,n_rec", [(640, 480, 8, 16, 1500), (640, 480, 8, 3, 2000), (320, 240, 16, 40, 300),
+                                                   (848, 480, 32, 7, 405), (640, 480, 8, 0, 1000)])
+def test_windowed_match_on_arbitrary_records(gpu, oracle_mod, w, h, cell, window, n_rec):
+    """Records as a caller may hand them in: several per cell, non-integer positions, positions outside the
+    image (bucket clamping), ragged counts.  The cell-indexed matcher must give the brute-force answer."""
+    torch, orbfe = gpu
+    ctx = orbfe.Context(w, h, cell=cell, min_arc=9, max_batch=4, max_features=0)
+    cap = ctx.cap
+    assert n_rec <= cap
+    rng = np.random.default_rng(cell * 1000 + window)
+    n = 4
+    rec = np.zeros((n, cap), dtype=orbfe.KEYPOINT_DTYPE)
+    cnt = np.array([n_rec, n_rec - 7, cap if cap < 3000 else n_rec, 1], np.int32)
+    base_desc = rng.integers(0, 256, (64, 32)).astype(np.uint8)  # few distinct descriptors -> many distance ties
+    for f in range(n):
+        m = cnt[f]
+        rec["x"][f, :m] = rng.uniform(-25, w + 25, m).astype(np.float32)
+        rec["y"][f, :m] = rng.uniform(-25, h + 25, m).astype(np.float32)
+        rec["x"][f, :m:3] = np.round(rec["x"][f, :m:3])
+        d = base_desc[rng.integers(0, 64, m)].copy()
+        flip = rng.random((m, 32)) < 0.05
+        d[flip] ^= rng.integers(1, 256, int(flip.sum())).astype(np.uint8)
+        rec["desc"][f, :m] = d
+    rec["x"][1, :50] = rec["x"][0, :50]  # exact coincidences and window-edge cases
+    rec["y"][1, :50] = rec["y"][0, :50] + window
+    d_rec, d_cnt = dev(torch, rec.view(np.uint8).reshape(-1)), dev(torch, cnt)
+    d_idx = torch.full(((n - 1) * cap,), -7, dtype=torch.int32, device="cuda")
+    d_dist = torch.full(((n - 1) * cap,), -7, dtype=torch.int32, device="cuda")
+    ctx.match_batch(d_rec.data_ptr(), d_cnt.data_ptr(), n, 1, window, 200, d_idx.data_ptr(), d_dist.data_ptr(), stream(torch))
+    idx = d_idx.cpu().numpy().reshape(n - 1, cap)
+    dist = d_dist.cpu().numpy().reshape(n - 1, cap)
+    hits = 0
+    for p in range(n - 1):
+        A, B = rec[p, :cnt[p]], rec[p + 1, :cnt[p + 1]]
+        ref_idx, ref_dist = _match_ref(oracle_mod, A, B, 1, window, 200)
+        np.testing.assert_array_equal(idx[p, :cnt[p]], ref_idx, err_msg="pair %d" % p)
+        np.testing.assert_array_equal(dist[p, :cnt[p]], ref_dist)
+        assert (idx[p, cnt[p]:] == -1).all()
+        hits += int((ref_idx >= 0).sum())
+    assert hits > 20
