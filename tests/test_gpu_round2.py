@@ -425,3 +425,89 @@ def test_windowed_match_on_arbitrary_records(gpu, oracle_mod, w, h, cell, window
         assert (idx[p, cnt[p]:] == -1).all()
         hits += int((ref_idx >= 0).sum())
     assert hits > 20
+
+
+# ------------------------------------------------------------------ BASELINE configs at their own sizes, vs the oracle
+@pytest.mark.parametrize("w,h,cfg", [
+    (1280, 720, dict(levels=8, cell=8, min_arc=9, max_features=2000)),    # C4's per-frame configuration
+    (848, 480, dict(levels=8, cell=8, min_arc=9, max_features=2000)),     # C3's
+    (640, 480, dict(levels=1, cell=16, min_arc=12, max_features=1000)),   # C1 "1000-feature" variant: cell 16, top-1000
+    (3840, 2160, dict(levels=12, cell=16, min_arc=9, max_features=8000)), # C5's
+])
+def test_ext_regime_at_baseline_sizes(gpu, oracle_mod, w, h, cfg):
+    from test_gpu_parity import _check_extract
+    torch, orbfe = gpu
+    kw = dict(n_rects=800 * (w * h) // (640 * 480), min_size=6, max_size=32)
+    frames = np.stack([synth.frame(w, h, 41, "rects", **kw), synth.frame(w, h, 42, "rects", n_rects=96)])
+    ctx, rec, cnt, soa = _run_extract(torch, orbfe, frames, want_soa=(w < 3000), **cfg)
+    total = _check_extract(oracle_mod, ctx, frames, rec, cnt, soa, **cfg)
+    assert cnt.max() <= cfg["max_features"]
+    if cfg["min_arc"] == 9:
+        assert cnt[0] == cfg["max_features"], "the dense scene fills the feature budget"
+    assert total > 250
+
+
+def _c5_rank(rank, world, port, out_path):
+    """One rank of the C5 rehearsal: every rank on cuda:0 (RCCL refuses two ranks on one device, so the
+    collective is gloo's), detection tiles sharded by rank, keys merged through orbfe.dist.merge_cell_keys."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (os.path.join(root, "oracle"), os.path.join(root, "jetracer-orbslam2_amd")):
+        sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    import orbfe
+    from orbfe import synth as sy
+    from orbfe.dist import merge_cell_keys
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w, h = 1280, 720
+    cfg = dict(levels=8, cell=16, min_arc=9, max_features=1500)
+    img = sy.frame(w, h, 12, "rects", n_rects=2400, min_size=6, max_size=32)
+    ctx = orbfe.Context(w, h, max_batch=1, **cfg)
+    s = torch.cuda.current_stream().cuda_stream
+    d_in = torch.from_numpy(img).cuda()
+    ctx.build_pyramid(d_in.data_ptr(), w, w * h, 1, s)
+    ctx.detect_batch_shard(1, rank, world, s)
+    keys = torch.zeros(ctx.K, dtype=torch.int32, device="cuda")
+    ctx.export_cell_keys(1, keys.data_ptr(), s)
+    torch.cuda.synchronize()
+    mine = int((keys > 0).sum())
+    hk = keys.cpu()
+    merge_cell_keys(hk)  # all_reduce(MAX) over the ranks
+    keys.copy_(hk)
+    ctx.import_cell_keys(1, keys.data_ptr(), s)
+    rec = torch.zeros(ctx.cap * 52, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ctx.describe_batch(1, rec.data_ptr(), cnt.data_ptr(), None, s)
+    torch.cuda.synchronize()
+    np.savez(out_path % rank, rec=rec.cpu().numpy(), cnt=cnt.cpu().numpy(), mine=mine)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_c5_two_rank_rehearsal_through_merge_cell_keys(gpu, oracle_mod, tmp_path):
+    """The C5 flow with 2 real ranks (processes) sharing the test GPU: shard -> export -> merge_cell_keys
+    (gloo all-reduce MAX) -> import -> describe; both ranks must end with the oracle's records."""
+    import socket
+    import torch.multiprocessing as mp
+    torch, orbfe = gpu
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_c5_rank, args=(2, port, out), nprocs=2, join=True)
+    w, h = 1280, 720
+    cfg = dict(levels=8, cell=16, min_arc=9, max_features=1500)
+    img = synth.frame(w, h, 12, "rects", n_rects=2400, min_size=6, max_size=32)
+    ref = oracle_mod.extract_frame(img, oracle_mod.make_config(w, h, **cfg))
+    partial = []
+    for r in range(2):
+        got = np.load(out % r)
+        n = int(got["cnt"][0])
+        assert n == ref["count"] == 1500
+        assert got["rec"].view(orbfe.KEYPOINT_DTYPE)[:n].tobytes() == ref["records"].tobytes()
+        partial.append(int(got["mine"]))
+    assert all(0 < p for p in partial), "each rank detected a part of the cells"
