@@ -268,9 +268,9 @@ __device__ inline uint32_t compass4(uint32_t C, uint32_t Wd, uint32_t Ed, uint32
     uint32_t out = 0;
 #pragma unroll
     for (int h = 0; h < 2; h++) { // h = 0: bytes 0,2 (pixels 0,2); h = 1: bytes 1,3 (pixels 1,3)
-        const uint32_t m = 0x00FF00FFu;
-        const us2 c = U2((C >> (8 * h)) & m), w = U2((Wd >> (8 * h)) & m), e = U2((Ed >> (8 * h)) & m),
-                  n = U2((Nd >> (8 * h)) & m), s = U2((Sd >> (8 * h)) & m);
+        // bytes 0,2 (h = 0: one v_and) or 1,3 (h = 1: one v_perm) of a dword as two 16-bit lanes
+        auto lanes = [h](uint32_t x) { return U2(h ? __builtin_amdgcn_perm(0u, x, 0x0C030C01u) : (x & 0x00FF00FFu)); };
+        const us2 c = lanes(C), w = lanes(Wd), e = lanes(Ed), n = lanes(Nd), s = lanes(Sd);
         const us2 hi = c + U2(t2), lo = ssub(c, U2(t2));
         const us2 a = pmax(n, s), b = pmin(n, s), cc = pmax(e, w), d = pmin(e, w);
         const us2 m1 = pmin(a, cc), m2 = pmax(b, d);
@@ -335,7 +335,10 @@ struct StageTiles {
     int resp_pitch[8]; // ... and its pitch in floats
 };
 
-template <bool STAGE>
+// ARC = the minimum arc length as a compile-time constant (9..12): the compass test's variant and the
+// closed-form arc test then carry no run-time selects (8 fewer instructions per compass trip, ~10 per
+// ring-test batch).
+template <bool STAGE, int ARC>
 __global__ void __launch_bounds__(256)
 detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc *__restrict__ tiles,
                    uint32_t *__restrict__ cellkey, int tile_first, int tile_step, StageTiles st)
@@ -438,7 +441,7 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
     // ---- B: compass pre-test, 4 pixels per lane; score-tile row r <-> image y0 - 1 + r,
     //         pixel-tile column px <-> image x0 - 4 + px
     const uint32_t t2 = (uint32_t)g.threshold * 0x00010001u;
-    const bool need3 = g.arc >= 12;
+    constexpr bool need3 = ARC >= 12;
     int n1 = 0; // wave-uniform fill level of q1
     // Task = one dword group q (pixels px = 4q .. 4q+3) of score row r.  The first kMainTrips
     // trips cover the tile proper (rows 1..kTileH, groups 1..16, 16 rows per trip: no division in
@@ -511,7 +514,7 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
         if (i < n1) {
             e = q1[i];
             const int r = e >> 7, px = e & 127;
-            const int sc = fast_score_packed(s_px + (r + 3) * kPxW + px, t2, g.arc);
+            const int sc = fast_score_packed(s_px + (r + 3) * kPxW + px, t2, ARC);
             if (sc) {
                 s_sc[r * kScPitch + px - 3] = (uint16_t)sc;
                 pos = r >= 1 && r <= kTileH && px >= 4 && px < 4 + kTileW;
@@ -1426,6 +1429,18 @@ match_batch_256_kernel(const Desc8 *__restrict__ mdesc, const float2 *__restrict
     }
 }
 
+template <bool STAGE>
+static void launch_detect_tiles(const DeviceGeom &g, dim3 grid, hipStream_t stream, const uint8_t *pyr, const TileDesc *tiles,
+                                uint32_t *cellkey, int tile_first, int tile_step, const StageTiles &st)
+{
+    switch (g.arc) { // validated to 9..12 where the geometry is built
+    case 9: hipLaunchKernelGGL((detect_tile_kernel<STAGE, 9>), grid, dim3(256), 0, stream, g, pyr, tiles, cellkey, tile_first, tile_step, st); break;
+    case 10: hipLaunchKernelGGL((detect_tile_kernel<STAGE, 10>), grid, dim3(256), 0, stream, g, pyr, tiles, cellkey, tile_first, tile_step, st); break;
+    case 11: hipLaunchKernelGGL((detect_tile_kernel<STAGE, 11>), grid, dim3(256), 0, stream, g, pyr, tiles, cellkey, tile_first, tile_step, st); break;
+    default: hipLaunchKernelGGL((detect_tile_kernel<STAGE, 12>), grid, dim3(256), 0, stream, g, pyr, tiles, cellkey, tile_first, tile_step, st); break;
+    }
+}
+
 // Stage API: cell keys (left in the caller's d_score buffer, 4 bytes per cell) -> the reference's feature
 // grid: score as float in place, position, level (nms.cu:246-252; empty cells: 0, (0,0), 0 -- Q5)
 __global__ void stage_decode_kernel(int K, int cells_x, int cell0, float *__restrict__ score_and_key,
@@ -1480,8 +1495,7 @@ int launch_detect_stage(const orbfe_pyramid_level *lv, int n_levels, int thresho
     uint32_t *keys = reinterpret_cast<uint32_t *>(d_score); // 4 bytes per cell: the key, then (decode) the score
     if (hipMemsetAsync(keys, 0, (size_t)g.K * sizeof(uint32_t), stream) != hipSuccess) return ORBFE_ERR_HIP;
     if (n_tiles > 0)
-        hipLaunchKernelGGL(detect_tile_kernel<true>, dim3(n_tiles, 1), dim3(256), 0, stream, g, lv[0].image, nullptr, keys,
-                           0, 1, st);
+        launch_detect_tiles<true>(g, dim3(n_tiles, 1), stream, lv[0].image, nullptr, keys, 0, 1, st);
     hipLaunchKernelGGL(stage_decode_kernel, dim3((g.K + 255) / 256), dim3(256), 0, stream, g.K, g.cells_x, g.cell, d_score,
                        d_pos, d_level);
     return hipGetLastError() == hipSuccess ? ORBFE_OK : ORBFE_ERR_HIP;
@@ -1878,8 +1892,8 @@ int orbfe_detect_batch_shard(orbfe_ctx *ctx, int n_frames, int shard_index, int 
     // levels and of busy / empty image regions)
     const int n_mine = ctx->n_tiles > shard_index ? (ctx->n_tiles - shard_index + shard_count - 1) / shard_count : 0;
     if (n_mine > 0)
-        hipLaunchKernelGGL(detect_tile_kernel<false>, dim3(n_mine, n_frames), dim3(256), 0, S(stream), g, ctx->d_pyr,
-                           ctx->d_tiles, ctx->d_cellkey, shard_index, shard_count, StageTiles{});
+        launch_detect_tiles<false>(g, dim3(n_mine, n_frames), S(stream), ctx->d_pyr, ctx->d_tiles, ctx->d_cellkey,
+                                   shard_index, shard_count, StageTiles{});
     CTX_LAUNCH_CHECK(ctx, "detect_batch");
     return ORBFE_OK;
 }
