@@ -218,6 +218,8 @@ def main():
                                                            "0 = the mode's default")
     ap.add_argument("--scene", choices=("dense", "survey"), default="dense")
     ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic frames per rank (repeated to fill the batch)")
+    ap.add_argument("--prewarm", type=int, default=100,
+                    help="untimed steps issued before the warm-up steps so that the clocks have settled (not counted)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (survey scene, no-gather rate)")
     ap.add_argument("--rgb", action="store_true",
@@ -260,9 +262,16 @@ def main():
     from orbfe.dist import RcclComm, gather_keypoints_async, merge_cell_keys, shard_range
 
     share = os.environ.get("ORBFE_BENCH_SHARE_GPU") == "1"  # rehearsal on a 1-GPU box: every rank on cuda:0, gloo
+    # ORBFE_BENCH_FORCE_COMM=1: run the N > 1 code path (torch.distributed nccl + the C++/RCCL communicator
+    # and the gather inside the timed region) with a single rank -- everything but the xGMI transport
+    force_comm = os.environ.get("ORBFE_BENCH_FORCE_COMM") == "1" and world == 1
+    multi = world > 1 or force_comm
     comm = None
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if share:
             local_rank = 0
@@ -277,14 +286,23 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    if world > 1 and not share:
+    if multi and not share:
         def exchange(ident):  # rank 0's RCCL unique id reaches the other ranks through torch.distributed
             t = torch.zeros(128, dtype=torch.uint8, device=dev)
             if rank == 0:
                 t.copy_(torch.frombuffer(bytearray(ident), dtype=torch.uint8))
             dist.broadcast(t, 0)
             return bytes(t.cpu().numpy().tobytes())
-        comm = RcclComm(rank, world, local_rank, exchange)
+        try:
+            comm = RcclComm(rank, world, local_rank, exchange)
+        except Exception as e:  # keep the run alive on torch.distributed's own RCCL gather, and say so
+            sys.stderr.write("bench.py: liborbfe_dist.so communicator unavailable (%s); using torch.distributed\n" % e)
+            comm = None
+        ok = torch.tensor([1 if comm is not None else 0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # all ranks take the same path
+        if int(ok.item()) == 0 and comm is not None:
+            comm.close()
+            comm = None
 
     m = MODES[args.mode]
     w, h = m["width"], m["height"]
@@ -322,7 +340,7 @@ def main():
     dst = torch.zeros(max(n_pairs, 1) * max(cap, 1), dtype=torch.int32, device=dev)
     keys = torch.zeros(max(ctx.K if ctx else 1, 1), dtype=torch.int32, device=dev) if args.mode == "c5" else None
     equal_shards = m["scaling"] == "weak" or total % world == 0
-    gather_ok = world > 1 and args.mode != "c5" and equal_shards
+    gather_ok = multi and args.mode != "c5" and equal_shards
     gather_out = None
     if gather_ok and rank == 0:
         gather_out = [(torch.empty((world, B * cap * 52), dtype=torch.uint8, device=dev),
@@ -353,7 +371,7 @@ def main():
         if ev: ev[1].record()
         if args.mode == "c5":
             ctx.detect_batch_shard(B, rank, world, s)
-            if world > 1:  # partial per-cell keys -> element-wise MAX over the ranks -> back into the context
+            if multi:  # partial per-cell keys -> element-wise MAX over the ranks -> back into the context
                 ctx.export_cell_keys(B, keys.data_ptr(), s)
                 if comm is not None:
                     comm.allreduce_max_keys(keys.data_ptr(), ctx.K, s)
@@ -390,13 +408,18 @@ def main():
         if comm is not None:
             comm.sync()  # "gather complete on rank 0"
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
     def timed(frames, do_gather, record):
         state["frames"] = frames
         state["events"] = []
+        # the clocks take ~50 ms of load to settle (measured: 0.522 ms per step after 3 warm-up steps, 0.497
+        # after 20, 0.484 after 100, 0.482 over 200 timed steps): settle first, then the W warm-up steps
+        for _ in range(args.prewarm):
+            run_step(False, do_gather)
+        sync()
         for _ in range(args.warmup):
             run_step(False, do_gather)
         sync()
@@ -409,7 +432,7 @@ def main():
         kp_local = int(counts.sum())
         prs = [int(counts[k * m["stride"]] * counts[k * m["stride"] + 1]) for k in range(n_pairs)]
         pairs_local = int(sum(prs))
-        if world > 1:
+        if multi:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev if not share else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -530,14 +553,14 @@ def main():
                        "scene": ("dense: 800 rectangles of 6..32 px per 640x480 of area + noise (fills the feature budget)"
                                  if args.scene == "dense" else
                                  "survey: SURVEY.md 8d generator, 96 rectangles up to a fifth of the frame + -3..3 noise"),
-                       "distinct_frames_per_rank": int(len(base)),
+                       "distinct_frames_per_rank": int(len(base)), "prewarm_steps": args.prewarm,
                        "frames_per_gpu_per_step": B, "frames_per_step": R["frames_total"],
                        "keypoints_per_frame": R["kp_total"] / max(R["frames_total"], 1),
                        "collective": (("RCCL (liborbfe_dist.so: grouped ncclSend/ncclRecv, %s) gather of 52-byte keypoint "
                                        "records + counts to rank 0 inside the timed region, overlapped with the next step"
                                        % ("exact length" if args.exact_gather else "fixed stride")) if use_gather and comm
-                                      else "torch.distributed gloo gather (shared-GPU rehearsal)" if use_gather
-                                      else "RCCL all-reduce(MAX) of the per-cell keys (liborbfe_dist.so)" if (args.mode == "c5" and world > 1)
+                                      else "torch.distributed gather (%s)" % ("gloo, shared-GPU rehearsal" if share else "nccl = RCCL") if use_gather
+                                      else "RCCL all-reduce(MAX) of the per-cell keys (liborbfe_dist.so)" if (args.mode == "c5" and multi)
                                       else "none in the data path; barrier + timing reductions only")},
             "frames_per_s": R["frames_total"] * args.steps / elapsed,
             "matcher_gpairs_per_s": (R["pairs_local"] / (stages["match"] * 1e-3) / 1e9) if stages["match"] > 0 else None,
@@ -555,7 +578,7 @@ def main():
             out["cpu_baseline"] = None
     if comm is not None:
         comm.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

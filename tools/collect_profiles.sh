@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-extras"
+BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-extras --mode ${MODE:-c2}"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o run -- $BENCH --steps 20 --warmup 3 > "$OUT/trace.log" 2>&1
 cp "$(find "$OUT/trace" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o run -- $BENCH --steps 3 --warmup 1 > /dev/null 2>&1
@@ -20,7 +20,7 @@ rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_
     --output-format csv -d "$OUT/pmc_sq2" -o run -- $BENCH --steps 3 --warmup 1 > /dev/null 2>&1
 python3 "$ROOT/tools/pmc_summary.py" "$OUT/pmc_sq1" "$OUT/pmc_sq2" > "$OUT/pmc_sq.json"
 cd "$ROOT"
-python3 tools/make_traffic_json.py "$OUT/pmc_traffic.json" c2 "$OUT/traffic.json"
-python3 bench.py --steps 20 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"
+python3 tools/make_traffic_json.py "$OUT/pmc_traffic.json" "$OUT/pmc_sq.json" ${MODE:-c2} "$OUT/traffic.json"
+python3 bench.py --mode ${MODE:-c2} --steps 20 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"
 rm -rf "$OUT"/trace "$OUT"/pmc_fetch "$OUT"/pmc_write "$OUT"/pmc_sq1 "$OUT"/pmc_sq2
 ls -la "$OUT"

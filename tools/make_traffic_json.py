@@ -1,43 +1,48 @@
 #!/usr/bin/env python3
-"""Turn a pmc_summary JSON (FETCH_SIZE / WRITE_SIZE per kernel, separate rocprofv3 --pmc
-passes) into profiles/traffic.json: HBM-side bytes per launch of each bench stage.
-Corrections (MI355X_MICROARCH.md, HBM section; re-checked with tools/calib_copy on this
-pool: a 512 MiB read reports FETCH_SIZE = 262146 KiB for 4-byte and for 16-byte loads):
+"""Turn pmc_summary JSONs (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes and an SQ pass) into
+profiles/traffic.json: per bench stage, HBM-side bytes per launch and VALU wave-instructions per launch.
+Corrections (MI355X_MICROARCH.md, HBM section; re-checked with tools/calib_copy on this pool: a
+512 MiB read reports FETCH_SIZE = 262146 KiB for 4-byte and for 16-byte loads):
 read bytes = FETCH_SIZE * 1024 * 2, write bytes = WRITE_SIZE * 1024.
-usage: make_traffic_json.py <pmc_summary.json> <mode> <out.json>"""
+usage: make_traffic_json.py <pmc_traffic.json> <pmc_sq.json> <mode> <out.json>"""
 import json
 import sys
 
-src, mode, out = sys.argv[1:4]
+src, sq, mode, out = sys.argv[1:5]
 d = json.load(open(src))
+q = json.load(open(sq))
+
+STAGES = {
+    "pyramid": ["pyramid_fused_kernel", "blur_batch_kernel", "halfsample_batch_kernel"],
+    "detect": ["detect_tile_kernel"],
+    "describe": ["select_kernel", "describe_tile_kernel", "describe_kernel"],
+    "match": ["match_gather_kernel", "match_batch_256_kernel", "match_batch_ref_kernel", "match_expand_kernel",
+              "match_mfma_kernel", "match_bucket_kernel", "match_window_kernel"],
+}
 
 
-def b(prefix):
+def per_launch(table, prefix, fn):
     tot = 0.0
-    for k, v in d.items():
+    for k, v in table.items():
         if prefix in k:
-            n = 1
-            r = v.get("FETCH_SIZE", {}).get("avg", 0.0) * 1024 * 2
-            w = v.get("WRITE_SIZE", {}).get("avg", 0.0) * 1024
-            if "halfsample" in k:
-                n = 7  # 7 launches per step (levels 1..7); avg is per launch
-            tot += n * (r + w)
+            n = 7 if "halfsample" in k else 1  # 7 launches per step (levels 1..7); avg is per launch
+            tot += n * fn(v)
     return tot
 
 
-stages = {
-    "pyramid": b("pyramid_fused_kernel") + b("blur_batch_kernel") + b("halfsample_batch_kernel"),
-    "detect": b("detect_tile_kernel"),
-    "describe": b("select_kernel") + b("describe_kernel"),
-    "match": b("match_gather_kernel") + b("match_batch_256_kernel") + b("match_batch_ref_kernel")
-             + b("match_expand_kernel") + b("match_mfma_kernel"),
-}
+def bytes_of(v):
+    return v.get("FETCH_SIZE", {}).get("avg", 0.0) * 1024 * 2 + v.get("WRITE_SIZE", {}).get("avg", 0.0) * 1024
+
+
+stages = {s: sum(per_launch(d, p, bytes_of) for p in ks) for s, ks in STAGES.items()}
+valu = {s: sum(per_launch(q, p, lambda v: v.get("SQ_INSTS_VALU", {}).get("avg", 0.0)) for p in ks) for s, ks in STAGES.items()}
 try:
     allj = json.load(open(out))
 except Exception:
     allj = {}
+stages["valu_wave_instructions"] = valu
 allj[mode] = stages
-allj["_note"] = ("HBM-side bytes per stage launch (256 frames), from rocprofv3 --pmc FETCH_SIZE and "
-                 "--pmc WRITE_SIZE passes; reads doubled per the gfx950 correction")
+allj["_note"] = ("per stage launch (256 frames): HBM-side bytes from rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE "
+                 "passes (reads doubled per the gfx950 correction) and VALU wave-instructions from an SQ_INSTS_VALU pass")
 json.dump(allj, open(out, "w"), indent=1, sort_keys=True)
 print(json.dumps(stages))
