@@ -779,7 +779,7 @@ describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__re
     constexpr int kRows = G::kRows, kPitch = G::kPitch, kPatchBytes = G::kPatchBytes;
     // + 256 bytes: the last moment step of the last patch reads (zero-weighted) bytes past it
     __shared__ __attribute__((aligned(16))) uint8_t s_patch[4 * kKpw * kPatchBytes + 256];
-    static_assert(G::kStart + G::kMom * 256 + 15 <= kPatchBytes + 256, "moment reads stay inside s_patch");
+    static_assert(G::kStart + G::kMom * 256 + 15 + 4 <= kPatchBytes + 256, "moment reads stay inside s_patch");
 
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // scalar: wave-uniform
@@ -883,12 +883,21 @@ describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__re
         int phase = kx[0] - R - kax[0];
 #pragma unroll
         for (int it = 1; it < kKpw; it++) phase = (row & 3) == it ? kx[it] - R - kax[it] : phase;
-        const uint32_t aaddr = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t *)wpatch +
-                               (uint32_t)((row & 3) * kPatchBytes + G::kStart + (row >> 2) * 64 + (lane >> 4) * 16 + phase);
+        // 16 bytes from an arbitrary byte address = 5 aligned dwords realigned by v_alignbyte (byte-misaligned
+        // wide LDS reads are served one lane at a time on gfx950: tools/lds_unaligned_rate.hip)
+        const int abyte = (row & 3) * kPatchBytes + G::kStart + (row >> 2) * 64 + (lane >> 4) * 16 + phase;
+        const uint32_t *a32 = reinterpret_cast<const uint32_t *>(wpatch + (abyte & ~3));
+        const uint32_t ash = (uint32_t)abyte & 3u;
         u32x4 av[G::kMom];
 #pragma unroll
-        for (int ks = 0; ks < G::kMom; ks++) // the waits are per read (in-flight registers never leave an asm block)
-            asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(av[ks]) : "v"(aaddr), "n"(ks * 256) : "memory");
+        for (int ks = 0; ks < G::kMom; ks++) {
+            const uint32_t *q = a32 + ks * 64;
+            const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+            av[ks].x = __builtin_amdgcn_alignbyte(d1, d0, ash);
+            av[ks].y = __builtin_amdgcn_alignbyte(d2, d1, ash);
+            av[ks].z = __builtin_amdgcn_alignbyte(d3, d2, ash);
+            av[ks].w = __builtin_amdgcn_alignbyte(d4, d3, ash);
+        }
         v4i acc = {0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < G::kMom; ks++) {
@@ -1751,8 +1760,12 @@ int orbfe_create(const orbfe_config *cfg, orbfe_ctx **out)
         if (e == hipSuccess) e = hipMemcpy(ctx->d_momw_tile, wt.data(), wt.size(), hipMemcpyHostToDevice);
     }
     {
+        // Few keypoints per 64x64 tile (the reference regime: one per 32-px cell = 4 per tile): staging a private
+        // patch per keypoint moves less than staging every tile; from ~8 per tile on the tile kernel wins.
+        const int n_tiles = ((g.W + 63) / 64) * ((g.H + 63) / 64);
+        ctx->describe_patch = g.cap < 8 * n_tiles;
         const char *v = getenv("ORBFE_DESCRIBE"); // A/B timing of the two describe kernels on one box
-        ctx->describe_patch = v && !strcmp(v, "patch");
+        if (v) ctx->describe_patch = !strcmp(v, "patch");
     }
     if (g.cap <= kMmaMaxKeypoints) { // scratch of the matrix-core matcher
         if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_mexp, B * ctx->cap_pad * 128);
