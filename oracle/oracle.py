@@ -169,7 +169,8 @@ def compute_fast_angle(pos, score, img):
     return angle
 
 
-def calc_orb(angle, pos, img, angle_in_radians=0):
+def calc_orb(angle, pos, img, angle_in_radians=0, fma=False):
+    """fma=True: GET_VALUE's sums contracted into FMAs (exposure probe, see oracle_calc_orb_fma)."""
     img = np.ascontiguousarray(img, dtype=np.uint8)
     pos = np.ascontiguousarray(pos, dtype=np.float32)
     angle = np.ascontiguousarray(angle, dtype=np.float32)
@@ -177,8 +178,8 @@ def calc_orb(angle, pos, img, angle_in_radians=0):
     n = pos.shape[0]
     desc = np.zeros((n, 32), dtype=np.uint8)
     d32 = np.zeros(n, dtype=np.uint32)
-    lib().oracle_calc_orb(_p(angle), _p(pos), _p(desc), _p(d32), _p(img), w, w, h, n,
-                          angle_in_radians)
+    fn = lib().oracle_calc_orb_fma if fma else lib().oracle_calc_orb
+    fn(_p(angle), _p(pos), _p(desc), _p(d32), _p(img), w, w, h, n, angle_in_radians)
     return desc, d32
 
 

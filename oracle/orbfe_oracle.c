@@ -438,9 +438,9 @@ void oracle_compute_fast_angle(float *angle, const float *pos, const float *scor
  * EXT v (angle_in_radians): the stored angle is used directly and the border guard grows
  * from 17 to 19 because the rotated pattern then reaches 18 px.
  * ------------------------------------------------------------------------------------ */
-void oracle_calc_orb(const float *d_angle, const float *d_pos, uint8_t *desc_tmp,
-                     uint32_t *desc32, const uint8_t *image, int image_pitch, int image_width,
-                     int image_height, int n, int angle_in_radians)
+static void calc_orb_impl(const float *d_angle, const float *d_pos, uint8_t *desc_tmp,
+                          uint32_t *desc32, const uint8_t *image, int image_pitch, int image_width,
+                          int image_height, int n, int angle_in_radians, int fma)
 {
     for (int id = 0; id < n; id++) {
         uint8_t *desc = desc_tmp + (size_t)id * 32;
@@ -466,8 +466,13 @@ void oracle_calc_orb(const float *d_angle, const float *d_pos, uint8_t *desc_tmp
                         float pxf = (float)pt[2 * (2 * k + e)];
                         float pyf = (float)pt[2 * (2 * k + e) + 1];
                         float m1 = pxf * b, m2 = pyf * a, m3 = pxf * a, m4 = pyf * b;
-                        int row = ly + orbfe_rn_int(m1 + m2);
-                        int col = lx + orbfe_rn_int(m3 - m4);
+                        float fr = m1 + m2, fc = m3 - m4;
+                        if (fma) { /* what nvcc's default contraction most likely makes of orb.cu:13-14 */
+                            fr = fmaf(pxf, b, m2);
+                            fc = fmaf(pxf, a, -m4);
+                        }
+                        int row = ly + orbfe_rn_int(fr);
+                        int col = lx + orbfe_rn_int(fc);
                         t[e] = image[(size_t)row * image_pitch + col];
                     }
                     val |= (t[0] < t[1]) << k;
@@ -482,6 +487,24 @@ void oracle_calc_orb(const float *d_angle, const float *d_pos, uint8_t *desc_tmp
             desc32[id] = d;
         }
     }
+}
+
+void oracle_calc_orb(const float *d_angle, const float *d_pos, uint8_t *desc_tmp, uint32_t *desc32,
+                     const uint8_t *image, int image_pitch, int image_width, int image_height, int n,
+                     int angle_in_radians)
+{
+    calc_orb_impl(d_angle, d_pos, desc_tmp, desc32, image, image_pitch, image_width, image_height, n, angle_in_radians, 0);
+}
+
+/* The same with GET_VALUE's sums contracted into FMAs, fmaf(x, b, y * a) and fmaf(x, a, -(y * b)): nvcc
+ * fuses by default (the reference's CMakeLists sets no -fmad=false), which products it fuses is not
+ * observable here.  NOT the parity definition (that is oracle_calc_orb, no contraction); it exists so
+ * that tests/test_fma_exposure.py can count how many descriptor bits the decision can move. */
+void oracle_calc_orb_fma(const float *d_angle, const float *d_pos, uint8_t *desc_tmp, uint32_t *desc32,
+                         const uint8_t *image, int image_pitch, int image_width, int image_height, int n,
+                         int angle_in_radians)
+{
+    calc_orb_impl(d_angle, d_pos, desc_tmp, desc32, image, image_pitch, image_width, image_height, n, angle_in_radians, 1);
 }
 
 /* ------------------------------------------------------------------------------------

@@ -70,6 +70,9 @@ void oracle_compute_fast_angle(float *angle, const float *pos, const float *scor
                                const uint8_t *img, int pitch, int w, int h, int n);
 void oracle_calc_orb(const float *angle, const float *pos, uint8_t *desc_tmp, uint32_t *desc32,
                      const uint8_t *img, int pitch, int w, int h, int n, int angle_in_radians);
+/* calc_orb with GET_VALUE's sums as FMAs (nvcc's default contraction): exposure probe, not the parity definition */
+void oracle_calc_orb_fma(const float *angle, const float *pos, uint8_t *desc_tmp, uint32_t *desc32,
+                         const uint8_t *img, int pitch, int w, int h, int n, int angle_in_radians);
 /* f2: kernel_keypoint_pixel_to_point + deproject_pixel_to_point_double, cuda-align.cu:85-112, :282-364 */
 typedef struct oracle_intrinsics {
     int32_t width, height;
