@@ -142,6 +142,21 @@ _WIRE_SIGS = {  # include/orbfe_wire.h: the result record's wire format (host co
 }
 WIRE_EXPORTS = tuple(_WIRE_SIGS)
 
+
+class Imu(C.Structure):  # orbfe_imu, include/orbfe_pose.h
+    _fields_ = [("theta", C.c_float * 3), ("alpha", C.c_float), ("last_ts_gyro", C.c_double),
+                ("first_gyro", C.c_int32), ("first_accel", C.c_int32)]
+
+
+_POSE_SIGS = {  # include/orbfe_pose.h: f4, host code inside liborbfe.so
+    "orbfe_best_fit_transform": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
+    "orbfe_icp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "orbfe_imu_init": (None, [C.POINTER(Imu)]),
+    "orbfe_imu_process_gyro": (None, [C.POINTER(Imu), C.POINTER(C.c_float), C.c_double]),
+    "orbfe_imu_process_accel": (None, [C.POINTER(Imu), C.POINTER(C.c_float)]),
+}
+POSE_EXPORTS = tuple(_POSE_SIGS)
+
 _lib = None
 
 
@@ -155,7 +170,7 @@ def lib():
                                  "`make -C jetracer-orbslam2_amd/csrc` (needs hipcc; there is "
                                  "no CPU fallback)" % LIB_PATH)
         L = C.CDLL(LIB_PATH)
-        for name, (res, args) in list(_SIGS.items()) + list(_WIRE_SIGS.items()):
+        for name, (res, args) in list(_SIGS.items()) + list(_WIRE_SIGS.items()) + list(_POSE_SIGS.items()):
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args

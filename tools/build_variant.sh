@@ -12,7 +12,8 @@ F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectori
 /opt/rocm/bin/hipcc $F "$@" -c -o $OUT/batch.o $SRC/batch_kernels.hip &
 /opt/rocm/bin/hipcc $F -fno-honor-nans -mllvm -amdgpu-mfma-vgpr-form "$@" -c -o $OUT/mfma.o $SRC/match_mfma.hip &
 /opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC -ffp-contract=off -c -o $OUT/wire.o $SRC/wire_bson.cpp &
+/opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC -ffp-contract=off -c -o $OUT/pose.o $SRC/pose_host.cpp &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/liborbfe.so $OUT/stage.o $OUT/batch.o $OUT/mfma.o $OUT/wire.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/liborbfe.so $OUT/stage.o $OUT/batch.o $OUT/mfma.o $OUT/wire.o $OUT/pose.o
 rm -f $OUT/*.o
 echo $OUT/liborbfe.so
