@@ -1761,11 +1761,14 @@ int orbfe_create(const orbfe_config *cfg, orbfe_ctx **out)
     }
     {
         // Few keypoints per 64x64 tile (the reference regime: one per 32-px cell = 4 per tile): staging a private
-        // patch per keypoint moves less than staging every tile; from ~8 per tile on the tile kernel wins.
+        // patch per keypoint moves less than staging every tile; from ~8 per tile on the tile kernel wins
+        // (reference mode, 256 frames: 0.040 vs 0.053 ms; C4 at 8.3 per tile: 0.078 vs 0.072).  The patch kernel
+        // also needs enough keypoints in the call to fill the chip (describe_batch checks that: one 4K frame
+        // with 3.9 per tile runs 0.077 ms as patches, 0.060 as 2040 tiles).
         const int n_tiles = ((g.W + 63) / 64) * ((g.H + 63) / 64);
-        ctx->describe_patch = g.cap < 8 * n_tiles;
+        ctx->describe_patch = g.cap < 8 * n_tiles ? 1 : 0;
         const char *v = getenv("ORBFE_DESCRIBE"); // A/B timing of the two describe kernels on one box
-        if (v) ctx->describe_patch = !strcmp(v, "patch");
+        if (v) ctx->describe_patch = !strcmp(v, "patch") ? 2 : -1;
     }
     if (g.cap <= kMmaMaxKeypoints) { // scratch of the matrix-core matcher
         if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_mexp, B * ctx->cap_pad * 128);
@@ -1954,9 +1957,10 @@ int orbfe_describe_batch(orbfe_ctx *ctx, int n_frames, orbfe_keypoint *d_records
     if (soa) so = *soa;
     DeviceScope dev(ctx->cfg.device);
     if (!dev.ok) CTX_FAIL(ctx, ORBFE_ERR_HIP, "describe_batch: hipSetDevice(%d) failed", ctx->cfg.device);
+    const bool patch = ctx->describe_patch == 2 || (ctx->describe_patch == 1 && (long long)n_frames * g.cap >= 32768);
     hipLaunchKernelGGL(select_kernel, dim3(n_frames), dim3(kSelThreads), 0, S(stream), g, ctx->d_cellkey,
-                       ctx->describe_patch ? ctx->d_sel : nullptr, ctx->d_cellslot, ctx->d_selcount, d_counts, so);
-    if (ctx->describe_patch) {
+                       patch ? ctx->d_sel : nullptr, ctx->d_cellslot, ctx->d_selcount, d_counts, so);
+    if (patch) {
         if (g.angle_in_radians)
             hipLaunchKernelGGL(describe_kernel<19>, dim3((g.cap + 4 * kKpw - 1) / (4 * kKpw), n_frames), dim3(256), 0,
                                S(stream), g, ctx->d_pyr, ctx->d_sel, ctx->d_selcount, ctx->d_momw, d_records, so);

@@ -192,7 +192,7 @@ struct orbfe_ctx {
     int32_t *d_selcount = nullptr;  // [max_batch]
     uint16_t *d_cellslot = nullptr; // [max_batch][K] record slot of each cell's keypoint, 0xFFFF = not selected
     uint4 *d_momw_tile = nullptr;   // describe (tile form): int8 weight fragments of the moment MFMAs
-    bool describe_patch = false;    // ORBFE_DESCRIBE=patch: the per-keypoint-patch kernel (A/B timing)
+    int describe_patch = 0;         // 1: sparse regime, patch kernel for large calls; 2 / -1: forced by ORBFE_DESCRIBE=patch / tile
     uint8_t *d_mdesc = nullptr;     // [max_batch][cap][32]  matcher scratch: dense descriptors
     uint8_t *d_mpos = nullptr;      // [max_batch][cap] float2 matcher scratch: positions
     int32_t *d_bend = nullptr;      // [max_batch][K]   windowed matcher: end of every cell bucket in d_bsorted

@@ -511,3 +511,34 @@ def test_c5_two_rank_rehearsal_through_merge_cell_keys(gpu, oracle_mod, tmp_path
         assert got["rec"].view(orbfe.KEYPOINT_DTYPE)[:n].tobytes() == ref["records"].tobytes()
         partial.append(int(got["mine"]))
     assert all(0 < p for p in partial), "each rank detected a part of the cells"
+
+
+# ------------------------------------------------------------------ both describe kernels, forced
+@pytest.mark.parametrize("which", ["patch", "tile"])
+@pytest.mark.parametrize("cfg", [dict(levels=6), dict(levels=8, cell=8, min_arc=9, max_features=2000),
+                                 dict(levels=4, cell=64, min_arc=12), dict(levels=5, cell=16, min_arc=9, angle_in_radians=1)])
+def test_both_describe_kernels_match_the_oracle(gpu, oracle_mod, monkeypatch, which, cfg):
+    """The library picks the per-keypoint-patch or the tile describe kernel by keypoint density and call size;
+    ORBFE_DESCRIBE forces one (read when the context is created).  Both must equal the oracle in every regime."""
+    from test_gpu_parity import _check_extract, _mixed_frames
+    torch, orbfe = gpu
+    monkeypatch.setenv("ORBFE_DESCRIBE", which)
+    frames = _mixed_frames(640, 480)
+    ctx, rec, cnt, soa = _run_extract(torch, orbfe, frames, **cfg)
+    total = _check_extract(oracle_mod, ctx, frames, rec, cnt, soa, **cfg)
+    assert total > 50
+
+
+def test_reference_regime_at_bench_size_uses_the_patch_kernel_and_matches(gpu, oracle_mod):
+    """256 frames in the reference regime: large sparse calls take the patch kernel (n_frames * cap >= 32768)."""
+    torch, orbfe = gpu
+    w, h, n = 640, 480, 256
+    base = synth.frames(w, h, 4, 300, "rects", **synth.DENSE)
+    frames = base[np.arange(n) % 4]
+    cfg = dict(levels=6)
+    ctx, rec, cnt, _ = _run_extract(torch, orbfe, frames, want_soa=False, **cfg)
+    ocfg = oracle_mod.make_config(w, h, levels=6)
+    for f in (0, 1, 2, 3, 255):
+        ref = oracle_mod.extract_frame(frames[f], ocfg)
+        assert cnt[f] == ref["count"] > 100
+        assert rec[f, :cnt[f]].tobytes() == ref["records"].tobytes()
