@@ -542,3 +542,33 @@ def test_reference_regime_at_bench_size_uses_the_patch_kernel_and_matches(gpu, o
         ref = oracle_mod.extract_frame(frames[f], ocfg)
         assert cnt[f] == ref["count"] > 100
         assert rec[f, :cnt[f]].tobytes() == ref["records"].tobytes()
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_cpp_multi_gpu_port(gpu, oracle_mod, tmp_path, exact):
+    """examples/multi_gpu_port.cpp: C++ host, one thread + context + RCCL rank per GPU (the reference's
+    thread-per-stream model, SlamGpuPipeline.cpp:43-50), frames sharded, records gathered on rank 0 -- run with
+    the one GPU of the test box; rank 0's gathered records must be the oracle's, frame by frame."""
+    import os
+    import subprocess
+    torch, orbfe = gpu
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "multi_gpu_port")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    w, h, n = 640, 480, 6
+    frames = np.stack([synth.frame(w, h, 60 + i, "rects", n_rects=96 if i % 2 else 800, min_size=6, max_size=None if i % 2 else 32)
+                       for i in range(n)])
+    fin, fout = str(tmp_path / "frames.bin"), str(tmp_path / "out.bin")
+    frames.tofile(fin)
+    subprocess.check_call([exe, "1", str(w), str(h), str(n), fin, fout] + (["exact"] if exact else []))
+    raw = np.fromfile(fout, np.uint8)
+    nf, cap = raw[:8].view(np.int32)
+    assert nf == n and cap == 2000
+    counts = raw[8:8 + 4 * n].view(np.int32)
+    rec = raw[8 + 4 * n:].view(orbfe.KEYPOINT_DTYPE).reshape(n, cap)
+    ocfg = oracle_mod.make_config(w, h, levels=8, cell=8, min_arc=9, max_features=2000)
+    for f in range(n):
+        ref = oracle_mod.extract_frame(frames[f], ocfg)
+        assert counts[f] == ref["count"]
+        assert rec[f, :counts[f]].tobytes() == ref["records"].tobytes()
+    assert counts.min() < 1500 < counts.max(), "ragged counts: the exact-length form ships fewer bytes"
