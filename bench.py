@@ -345,6 +345,9 @@ def main():
     if gather_ok and rank == 0:
         gather_out = [(torch.empty((world, B * cap * 52), dtype=torch.uint8, device=dev),
                        torch.empty((world, B), dtype=torch.int32, device=dev)) for _ in range(2)]
+        if not args.exact_gather:  # rank 0 extracts straight into its own block of the gathered arrays: no local copy
+            recs = [gather_out[b][0][0] for b in range(2)]
+            cnts = [gather_out[b][1][0] for b in range(2)]
     state = dict(frames=None, step=0, tickets=[0, 0], pending=[None, None], events=[])
 
     def run_step(record, do_gather):

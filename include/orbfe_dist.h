@@ -55,7 +55,9 @@ int orbfe_dist_shard_range(int n_total, int rank, int world, int *begin, int *en
  *                          orbfe_extract).  Every rank passes the same n_frames and cap.
  *   d_all_records        : root only: world * n_frames * cap records, rank-major (== frame order,
  *                          because shards are contiguous); d_all_counts: world * n_frames ints.
- *   exact == 0 : fixed stride -- every rank ships n_frames * cap * 52 bytes; nothing touches the host.
+ *   exact == 0 : fixed stride -- every rank ships n_frames * cap * 52 bytes; nothing touches the host.  A root
+ *                that extracted straight into its own block (d_records == d_all_records + root * n_frames * cap,
+ *                d_counts likewise) copies nothing.
  *   exact != 0 : variable length -- counts travel first and the host reads them (this call blocks
  *                until this rank's extraction has finished); every rank packs its valid records
  *                densely on the device and ships exactly sum(counts) * 52 bytes.  On the root,

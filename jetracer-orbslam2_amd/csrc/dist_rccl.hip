@@ -251,7 +251,8 @@ int orbfe_dist_gather_keypoints(orbfe_dist *d, const orbfe_keypoint *d_records, 
     const size_t rbytes = rstride * sizeof(orbfe_keypoint);
 
     // ---- counts (always fixed size)
-    if (is_root)
+    // (a root that extracts straight into its own block of the gathered arrays passes those addresses: no copy)
+    if (is_root && d_all_counts + (size_t)root * n_frames != d_counts)
         D_HIP(d, hipMemcpyAsync(d_all_counts + (size_t)root * n_frames, d_counts, cbytes, hipMemcpyDeviceToDevice, d->cs));
     if (d->world > 1) {
         D_NCCL(d, ncclGroupStart());
@@ -266,7 +267,7 @@ int orbfe_dist_gather_keypoints(orbfe_dist *d, const orbfe_keypoint *d_records, 
 
     if (!exact) {
         // ---- fixed stride: nothing touches the host
-        if (is_root)
+        if (is_root && d_all_records + (size_t)root * rstride != d_records)
             D_HIP(d, hipMemcpyAsync(d_all_records + (size_t)root * rstride, d_records, rbytes, hipMemcpyDeviceToDevice, d->cs));
         if (d->world > 1) {
             D_NCCL(d, ncclGroupStart());
@@ -299,6 +300,9 @@ int orbfe_dist_gather_keypoints(orbfe_dist *d, const orbfe_keypoint *d_records, 
         return t;
     };
     uint32_t *pack_dst;
+    if (is_root && d_all_records + (size_t)root * rstride == d_records)
+        D_FAIL(d, ORBFE_ERR_INVALID_ARG, "gather_keypoints: the exact-length form packs the root's records into its block "
+               "of d_all_records, which therefore cannot be the buffer they come from");
     if (is_root) {
         pack_dst = reinterpret_cast<uint32_t *>(d_all_records + (size_t)root * rstride);
     } else {
