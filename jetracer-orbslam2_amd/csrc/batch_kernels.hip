@@ -1532,7 +1532,7 @@ constexpr int kBucketThreads = 1024;
 __global__ void __launch_bounds__(kBucketThreads)
 match_bucket_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *__restrict__ counts, int cap, int first,
                     int stride, int K, int cells_x, int cells_y, float inv_cell, int32_t *__restrict__ bend_all,
-                    uint16_t *__restrict__ sorted_all)
+                    uint16_t *__restrict__ sorted_all, uint32_t *__restrict__ d32_all)
 {
     __shared__ int s_wave[kBucketThreads / 64];
     const int f = first + blockIdx.x * stride + 1; // the pair's curr frame
@@ -1547,6 +1547,12 @@ match_bucket_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *_
         const int b = bucket_coord(__uint_as_float(R[13 * (size_t)i + 1]), inv_cell, cells_y) * cells_x +
                       bucket_coord(__uint_as_float(R[13 * (size_t)i]), inv_cell, cells_x);
         atomicAdd(&bend[b], 1);
+        if (d32_all) { // reference-mode matching: the 32-bit "compressed" descriptor (orb.cu:145-169) of every record
+            uint32_t w[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) w[j] = R[13 * (size_t)i + 5 + j];
+            d32_all[(size_t)f * cap + i] = compress_words(w);
+        }
     }
     __syncthreads();
     // exclusive prefix sum over the K counts (the counts were made by L2 atomics: read them past this CU's L1)
@@ -1617,6 +1623,70 @@ match_window_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *_
     const bool ok = best != 0xFFFFFFFFu && bd <= max_dist;
     out_idx[(size_t)pk * cap + i] = ok ? bj : -1;
     if (out_dist) out_dist[(size_t)pk * cap + i] = ok ? bd : -1;
+}
+
+// Reference-mode matching (post_processing.cu:92-200) through the same cell index.  The reference's thread
+// visits the curr keypoints tile by tile (32 per tile), inside a tile of m entries in the order
+// j = (s + tid) % m, skips a tile when tid >= m (Q8), and keeps the FIRST strictly smaller distance: the
+// winner is the lexicographic minimum of (distance, visiting rank) with rank = 32 * tile + (j - tid) mod m
+// -- an order-free reduction, so only the few candidates inside the +-window cells have to be looked at
+// instead of all of them tile by tile.  Same result as match_batch_ref_kernel, bit for bit.
+__global__ void __launch_bounds__(256)
+match_window_ref_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *__restrict__ counts, int cap, int first,
+                        int stride, int K, int cells_x, int cells_y, float inv_cell, const int32_t *__restrict__ bend_all,
+                        const uint16_t *__restrict__ sorted_all, const uint32_t *__restrict__ d32_all, int window,
+                        int max_ham, int32_t *__restrict__ out_idx, int32_t *__restrict__ out_dist)
+{
+    int pk, blk;
+    xcd_remap(gridDim.x, gridDim.y, &pk, &blk);
+    const int p = first + pk * stride;
+    const int nA = clamp_count(counts[p], cap), nB = clamp_count(counts[p + 1], cap);
+    const int i = blk * 256 + threadIdx.x;
+    if (i >= cap) return;
+    uint32_t best = 0xFFFFFFFFu;
+    const int tid = i & 31;
+    if (i < nA && nB > 0) {
+        const uint32_t *A = reinterpret_cast<const uint32_t *>(records + (size_t)p * cap) + 13 * (size_t)i;
+        const uint32_t *B = reinterpret_cast<const uint32_t *>(records + (size_t)(p + 1) * cap);
+        const int32_t *bend = bend_all + (size_t)(p + 1) * K;
+        const uint16_t *sorted = sorted_all + (size_t)(p + 1) * cap;
+        const uint32_t *d32 = d32_all + (size_t)(p + 1) * cap;
+        const float ax = __uint_as_float(A[0]), ay = __uint_as_float(A[1]), win = (float)window;
+        uint32_t w[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) w[k] = A[5 + k];
+        const uint32_t da = compress_words(w);
+        const int bx0 = bucket_coord(ax - win, inv_cell, cells_x), bx1 = bucket_coord(ax + win, inv_cell, cells_x);
+        const int by0 = bucket_coord(ay - win, inv_cell, cells_y), by1 = bucket_coord(ay + win, inv_cell, cells_y);
+        for (int by = by0; by <= by1; by++) {
+            const int g0 = by * cells_x + bx0, g1 = by * cells_x + bx1;
+            int t = g0 > 0 ? bend[g0 - 1] : 0;
+            const int e = bend[g1];
+            for (; t < e; t++) {
+                const int j = sorted[t];
+                const int base = j & ~31, m = base + 32 >= nB ? nB - base : 32;
+                if (tid >= m) continue; // the reference's thread skips this (partial) tile
+                const uint32_t *r = B + 13 * (size_t)j;
+                if (fabsf(ax - __uint_as_float(r[0])) > win || fabsf(ay - __uint_as_float(r[1])) > win) continue;
+                const int hd = __popc(da ^ d32[j]);
+                if (hd >= max_ham) continue;
+                int rot = (j - base) - tid;
+                rot = rot < 0 ? rot + m : rot;
+                const uint32_t key = ((uint32_t)hd << 16) | (uint32_t)(base + rot);
+                best = key < best ? key : best;
+            }
+        }
+    }
+    int bj = -1, bd = -1;
+    if (best != 0xFFFFFFFFu) {
+        const int rank = (int)(best & 0xFFFFu), base = rank & ~31, m = base + 32 >= nB ? nB - base : 32;
+        int jl = (rank - base) + tid;
+        jl = jl >= m ? jl - m : jl;
+        bj = base + jl;
+        bd = (int)(best >> 16);
+    }
+    out_idx[(size_t)pk * cap + i] = bj;
+    if (out_dist) out_dist[(size_t)pk * cap + i] = bd;
 }
 
 } // namespace orbfe
@@ -1750,6 +1820,7 @@ int orbfe_create(const orbfe_config *cfg, orbfe_ctx **out)
     if (g.cap <= 65535) { // windowed 256-bit matching: cell buckets of the curr frames
         if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_bend, B * g.K * sizeof(int32_t));
         if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_bsorted, B * g.cap * sizeof(uint16_t));
+        if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_bd32, B * g.cap * sizeof(uint32_t));
     }
     ctx->cap_pad = (g.cap + 15) / 16 * 16;
     {
@@ -1801,6 +1872,7 @@ void orbfe_destroy(orbfe_ctx *ctx)
     if (ctx->d_mpos) (void)hipFree(ctx->d_mpos);
     if (ctx->d_bend) (void)hipFree(ctx->d_bend);
     if (ctx->d_bsorted) (void)hipFree(ctx->d_bsorted);
+    if (ctx->d_bd32) (void)hipFree(ctx->d_bd32);
     if (ctx->d_mexp) (void)hipFree(ctx->d_mexp);
     if (ctx->d_mkey) (void)hipFree(ctx->d_mkey);
     if (ctx->d_momw) (void)hipFree(ctx->d_momw);
@@ -2023,10 +2095,22 @@ int orbfe_match_pairs(orbfe_ctx *ctx, const orbfe_keypoint *d_records, const int
     DeviceScope dev(ctx->cfg.device);
     if (!dev.ok) CTX_FAIL(ctx, ORBFE_ERR_HIP, "match: hipSetDevice(%d) failed", ctx->cfg.device);
     dim3 grid((cap + 255) / 256, n_pairs), block(256);
-    if (mode == 0)
-        hipLaunchKernelGGL(match_batch_ref_kernel, grid, block, 0, S(stream), d_records, d_counts, cap, first, stride,
-                           (float)window, max_distance, d_idx, d_dist);
-    else {
+    if (mode == 0) {
+        const DeviceGeom &g = ctx->g;
+        const int wc = 2 * ((window + g.cell - 1) / g.cell) + 1; // cells per window edge, at most
+        if (ctx->d_bend && ctx->d_bd32 && n_frames <= ctx->cfg.max_batch && (long long)wc * wc * 4 <= (long long)g.K) {
+            const float inv_cell = 1.0f / (float)g.cell;
+            hipLaunchKernelGGL(match_bucket_kernel, dim3(n_pairs), dim3(kBucketThreads), 0, S(stream), d_records, d_counts,
+                               cap, first, stride, g.K, g.cells_x, g.cells_y, inv_cell, ctx->d_bend, ctx->d_bsorted,
+                               ctx->d_bd32);
+            hipLaunchKernelGGL(match_window_ref_kernel, grid, block, 0, S(stream), d_records, d_counts, cap, first, stride,
+                               g.K, g.cells_x, g.cells_y, inv_cell, ctx->d_bend, ctx->d_bsorted, ctx->d_bd32, window,
+                               max_distance, d_idx, d_dist);
+        } else {
+            hipLaunchKernelGGL(match_batch_ref_kernel, grid, block, 0, S(stream), d_records, d_counts, cap, first, stride,
+                               (float)window, max_distance, d_idx, d_dist);
+        }
+    } else {
         if (n_frames > ctx->cfg.max_batch)
             CTX_FAIL(ctx, ORBFE_ERR_CAPACITY, "match: n_frames %d > max_batch %d", n_frames, ctx->cfg.max_batch);
         if (window < 0 && ctx->d_mexp) { // all candidates, <= 16384 per frame: matrix cores
@@ -2042,7 +2126,7 @@ int orbfe_match_pairs(orbfe_ctx *ctx, const orbfe_keypoint *d_records, const int
         if (window >= 0 && ctx->d_bend && (long long)wc * wc * 4 <= (long long)g.K) {
             const float inv_cell = 1.0f / (float)g.cell; // exact: the cell is a power of two
             hipLaunchKernelGGL(match_bucket_kernel, dim3(n_pairs), dim3(kBucketThreads), 0, S(stream), d_records, d_counts, cap, first,
-                               stride, g.K, g.cells_x, g.cells_y, inv_cell, ctx->d_bend, ctx->d_bsorted);
+                               stride, g.K, g.cells_x, g.cells_y, inv_cell, ctx->d_bend, ctx->d_bsorted, (uint32_t *)nullptr);
             hipLaunchKernelGGL(match_window_kernel, grid, block, 0, S(stream), d_records, d_counts, cap, first, stride, g.K,
                                g.cells_x, g.cells_y, inv_cell, ctx->d_bend, ctx->d_bsorted, window, max_distance, d_idx,
                                d_dist);

@@ -197,6 +197,7 @@ struct orbfe_ctx {
     uint8_t *d_mpos = nullptr;      // [max_batch][cap] float2 matcher scratch: positions
     int32_t *d_bend = nullptr;      // [max_batch][K]   windowed matcher: end of every cell bucket in d_bsorted
     uint16_t *d_bsorted = nullptr;  // [max_batch][cap] windowed matcher: record indices sorted by cell
+    uint32_t *d_bd32 = nullptr;     // [max_batch][cap] reference-mode matcher: compressed 32-bit descriptors
     uint4 *d_mexp = nullptr;        // [max_batch][cap_pad][8]  MFMA matcher: descriptors as e2m1 fragments (cap <= 16384)
     float *d_mkey = nullptr;        // [max_batch][cap_pad]     MFMA matcher: -(popcount * 16384 + index)
     int cap_pad = 0;                // cap rounded up to 16

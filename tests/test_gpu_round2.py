@@ -572,3 +572,45 @@ def test_cpp_multi_gpu_port(gpu, oracle_mod, tmp_path, exact):
         assert counts[f] == ref["count"]
         assert rec[f, :counts[f]].tobytes() == ref["records"].tobytes()
     assert counts.min() < 1500 < counts.max(), "ragged counts: the exact-length form ships fewer bytes"
+
+
+@pytest.mark.parametrize("w,h,cell,window,maxham,n_rec", [(640, 480, 32, 2, 4, 300), (640, 480, 8, 5, 3, 1999), (320, 240, 16, 12, 33, 290),
+                                                         (848, 480, 32, 0, 1, 405), (640, 480, 8, 40, 2, 777)])
+def test_reference_matcher_through_the_cell_index(gpu, oracle_mod, w, h, cell, window, maxham, n_rec):
+    """Reference semantics (first strictly smaller distance in the rotated tile-of-32 visiting order, partial-tile
+    skip) computed as an order-free minimum of (distance, visiting rank) over the window's cells: must equal the
+    oracle's literal restatement of kernel_match_keypoints on records with MANY equal distances, several
+    keypoints per cell, positions outside the image and ragged counts (partial last tiles)."""
+    torch, orbfe = gpu
+    ctx = orbfe.Context(w, h, cell=cell, min_arc=9, max_batch=4, max_features=0)
+    cap = ctx.cap
+    assert n_rec <= cap
+    rng = np.random.default_rng(cell * 100 + window)
+    n = 4
+    rec = np.zeros((n, cap), dtype=orbfe.KEYPOINT_DTYPE)
+    cnt = np.array([n_rec, n_rec - 13, min(cap, n_rec + 1), 31], np.int32)
+    centres = rng.uniform(0, [w, h], size=(40, 2))  # shared by the frames: clustered positions, many candidates per window
+    base = rng.random((6, 32)) < 0.3
+    for f in range(n):
+        m = cnt[f]
+        pos = centres[rng.integers(0, 40, m)] + rng.normal(size=(m, 2)) * max(window, 1) * 0.8
+        rec["x"][f, :m] = np.round(pos[:, 0]).astype(np.float32)
+        rec["y"][f, :m] = np.round(pos[:, 1]).astype(np.float32)
+        # the 32-bit compression keeps "byte == 1" (orb.cu:156): six base words with one or two flips each, so
+        # that distances are small and ties are everywhere
+        ones = base[rng.integers(0, 6, m)] ^ (rng.random((m, 32)) < 0.03)
+        d = rng.integers(2, 256, (m, 32)).astype(np.uint8)
+        d[ones] = 1
+        rec["desc"][f, :m] = d
+    d_rec, d_cnt = dev(torch, rec.view(np.uint8).reshape(-1)), dev(torch, cnt)
+    d_idx = torch.full(((n - 1) * cap,), -7, dtype=torch.int32, device="cuda")
+    ctx.match_batch(d_rec.data_ptr(), d_cnt.data_ptr(), n, 0, window, maxham, d_idx.data_ptr(), None, stream(torch))
+    idx = d_idx.cpu().numpy().reshape(n - 1, cap)
+    hits = 0
+    for p in range(n - 1):
+        A, B = rec[p, :cnt[p]], rec[p + 1, :cnt[p + 1]]
+        ref_idx, _ = _match_ref(oracle_mod, A, B, 0, window, maxham)
+        np.testing.assert_array_equal(idx[p, :cnt[p]], ref_idx, err_msg="pair %d" % p)
+        assert (idx[p, cnt[p]:] == -1).all()
+        hits += int((ref_idx >= 0).sum())
+    assert hits > 20
