@@ -56,9 +56,23 @@ def digests(oracle, synth):
         idx, n = oracle.match_keypoints(pa, comp(a["desc"]), pb, comp(b["desc"]), 2, 4)
         d["match_ref"] = sha(idx)
         d["match_ref_count"] = int(n)
-        idx, dist = oracle.match256(a["desc"], b["desc"])
-        d["match256_idx"] = sha(idx)
+        idx256, dist = oracle.match256(a["desc"], b["desc"])
+        d["match256_idx"] = sha(idx256)
         d["match256_dist"] = sha(dist)
+        # round 2: the windowed 256-bit matcher, the matcher's compacted outputs and the reprojection
+        widx, wdist = oracle.match256(a["desc"], b["desc"], pa, pb, 6, 80)
+        d["match256_window_idx"] = sha(widx)
+        d["match256_window_dist"] = sha(wdist)
+        rng = np.random.default_rng(len(a) + 7)
+        pts_a = rng.normal(size=(max(len(a), 1), 3)) * [300, 200, 900] + [0, 0, 2500]
+        pts_b = rng.normal(size=(max(len(b), 1), 3)) * [300, 200, 900] + [0, 0, 2500]
+        kx, ky, pm, cm = oracle.match_compact(idx, pb, pts_a[:len(a)], pts_b[:len(b)])
+        d["compact_xy"] = sha(np.concatenate([kx, ky]))
+        d["compact_points"] = sha(np.concatenate([pm.reshape(-1), cm.reshape(-1)]))
+        intr = oracle.Intrinsics(w, h, w * 0.5 - 3.25, h * 0.5 + 1.5, 615.5, 615.25, 1,
+                                 (oracle.C.c_float * 5)(0.11, -0.23, 0.0007, -0.0004, 0.09))
+        T = np.array([[0.9995, 0.0, 0.0316, 12.5], [0.0, 1.0, 0.0, -3.25], [-0.0316, 0.0, 0.9995, 40.0], [0, 0, 0, 1.0]])
+        d["reproject"] = sha(oracle.reproject_points(pts_a[:len(a)], T, intr))
         out[name] = d
     return out
 
