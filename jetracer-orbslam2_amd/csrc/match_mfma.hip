@@ -19,19 +19,24 @@ namespace orbfe {
 //     fragment order -- per 16 keypoints: [k-step 2][lane 64][16 B], lane = 16 * (word & 3) +
 //     (keypoint & 15) -- so that one wave-wide 16-byte load IS the A or B operand (the order
 //     of the 256 bits inside K does not matter as long as both frames use the same one).  It
-//     also writes colkey[j] = -(|b_j| * S + j), S = 16384 (-1e30 for padding).
+//     also writes colkey[j] = -(|b_j| * S + j) / 2S, S = 16384 (-1e30 for padding).
 // (2) match_mfma_kernel: block = 128 queries of frame p (8 A fragments x 2 k-steps, resident
 //     in VGPRs), its 4 waves take every 4th block of 16 candidates of frame p + 1, streamed
-//     through a per-wave LDS ring by LDS-DMA.  B is block-scaled by 2^15 = 2S (E8M0 142) and
-//     the accumulator starts at colkey[j], so the MFMA pair itself yields
-//     key' = 2S a.b - S|b_j| - j = -(S (dist - |a|) + j) exactly, and the whole epilogue is a
-//     running maximum (one v_max3_f32 per two pairs): the maximum key' is the lexicographic
-//     minimum (dist, j), the same winner as the packed-key v_min_u32 of the VALU kernel.
-//     The 64 partial maxima per query (4 waves x 16 column classes) are reduced through LDS.
+//     through a per-wave LDS ring by LDS-DMA.  The accumulator starts at colkey[j], so the
+//     MFMA pair itself yields key' = a.b - |b_j| / 2 - j / 2S = -(S (dist - |a|) + j) / 2S
+//     exactly (8 integer + 15 fraction bits: every partial sum fits the f32 significand), and
+//     the whole epilogue is a running maximum (one v_max3_f32 per two pairs): the maximum key'
+//     is the lexicographic minimum (dist, j), the same winner as the packed-key v_min_u32 of
+//     the VALU kernel.  The 64 partial maxima per query (4 waves x 16 column classes) are
+//     reduced through LDS.
+//     Round 1 carried the keys as integers and let the instruction's block scale multiply B by
+//     2S; with both scales 0 hipcc emits the plain v_mfma_f32_16x16x128_f8f6f4 (a 64-bit
+//     encoding, no scale operands to read) and the same loop runs 5 % faster.
 // Measured (tools/mfma_probe.hip, MI355X): the MFMA alone issues at 19 T pairs/s; with the
 // epilogue as v_max_f32 the step structure tops out at 12.5 T (VALU issue does not overlap these
-// MFMAs), with v_max3_f32 at 14.7 T; the kernel reaches ~11 T.
+// MFMAs), with v_max3_f32 at 14.7 T; the kernel reaches ~12 T.
 constexpr int kMmaS = 16384;
+constexpr float kKeyUnit = 1.0f / (2 * kMmaS); // keys are carried as (integer key) / 2S: a power of two, exact
 constexpr int kMmaRows = 128;
 constexpr int kMmaLds = 68; // floats per query row in LDS: 64 + 4 keeps writes and b128 reads conflict-free
 constexpr int kRing = 4;                 // candidate blocks in flight per wave
@@ -70,7 +75,7 @@ match_expand_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *_
     const uint4 e = make_uint4(spread_bits_e2m1(word), spread_bits_e2m1(word >> 8), spread_bits_e2m1(word >> 16),
                                spread_bits_e2m1(word >> 24));
     mexp[(size_t)f * capP * 8 + (size_t)(i >> 4) * 128 + (w >> 2) * 64 + (w & 3) * 16 + (i & 15)] = e;
-    if (w == 0) mkey[(size_t)f * capP + i] = live ? -(float)(pop * kMmaS + i) : -1e30f;
+    if (w == 0) mkey[(size_t)f * capP + i] = live ? -(float)(pop * kMmaS + i) * kKeyUnit : -1e30f;
 }
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
@@ -159,11 +164,11 @@ match_mfma_kernel(const uint4 *__restrict__ mexp, const float *__restrict__ mkey
             const v8i d1 = (v8i){(int)p1.x, (int)p1.y, (int)p1.z, (int)p1.w, 0, 0, 0, 0};
 #pragma unroll
             for (int m = 0; m < 8; m++) {
-                // cbsz = blgp = 4: e2m1 operands; scales are E8M0 bytes: A x 2^0 (127), B x 2^15 (142)
-                v4f acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m][0], b0, cv, 4, 4, 0, 127, 0, 142);
-                v4f acd = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m][0], d0, dv, 4, 4, 0, 127, 0, 142);
-                acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m][1], b1, acc, 4, 4, 0, 127, 0, 142);
-                acd = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m][1], d1, acd, 4, 4, 0, 127, 0, 142);
+                // cbsz = blgp = 4: e2m1 operands; scale arguments 0, 0 select the unscaled instruction
+                v4f acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m][0], b0, cv, 4, 4, 0, 0, 0, 0);
+                v4f acd = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m][0], d0, dv, 4, 4, 0, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m][1], b1, acc, 4, 4, 0, 0, 0, 0);
+                acd = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m][1], d1, acd, 4, 4, 0, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; r++)
                     best[m][r] = __builtin_fmaxf(__builtin_fmaxf(best[m][r], acc[r]), acd[r]); // v_max3_f32
@@ -209,8 +214,8 @@ match_mfma_kernel(const uint4 *__restrict__ mexp, const float *__restrict__ mkey
         bool ok = active && i < nA && v > -1e29f;
         int bj = -1, bd = -1;
         if (ok) {
-            const int nk = -(int)v;                                       // S * (dist - |a_i|) + j
-            const int pop_a = (-(int)mkey[(size_t)p * capP + i]) >> 14; // |a_i|
+            const int nk = -(int)(v * (2 * kMmaS));                                       // S * (dist - |a_i|) + j
+            const int pop_a = (-(int)(mkey[(size_t)p * capP + i] * (2 * kMmaS))) >> 14; // |a_i|
             bj = nk & (kMmaS - 1);
             bd = pop_a + (nk >> 14);
             ok = bd <= max_dist;
