@@ -93,6 +93,28 @@ halfsample_batch_kernel(uint8_t *__restrict__ pyr, size_t fstride, size_t src_of
     *reinterpret_cast<uint32_t *>(base + dst_off + (size_t)y * dst_pitch + x0) = out;
 }
 
+// a3 batch  the small levels (8 and up: at most 1/256 of the frame's width and height) of one frame
+// in ONE workgroup, level after level with a barrier in between, instead of one launch per level:
+// a 12-level 4K pyramid is launch-bound (4 launches of ~100 pixels each).
+__global__ void __launch_bounds__(256)
+pyramid_tail_kernel(DeviceGeom g, uint8_t *__restrict__ pyr, int first_level)
+{
+    uint8_t *fb = pyr + (size_t)blockIdx.x * g.frame_stride;
+    for (int l = first_level; l < g.L; l++) {
+        const int dw = g.lv[l].w, dh = g.lv[l].h;
+        if (dw == 0 || dh == 0) break;
+        const uint8_t *src = fb + g.lv[l - 1].offset;
+        uint8_t *dst = fb + g.lv[l].offset;
+        const int sp = g.lv[l - 1].pitch, dp = g.lv[l].pitch;
+        for (int i = threadIdx.x; i < dw * dh; i += 256) {
+            const int y = i / dw, x = i - y * dw;
+            const uint8_t *q = src + (size_t)(2 * y) * sp + 2 * x;
+            dst[(size_t)y * dp + x] = (uint8_t)(((unsigned)q[0] + q[1] + q[sp] + q[sp + 1]) >> 2);
+        }
+        __syncthreads(); // level l is complete (and visible to this workgroup) before level l + 1 reads it
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // a2 + a3 fused: blur and ALL halvings of one 128x128 level-0 tile in one workgroup (levels
 // 0..7; 2^7 = 128).  The reference's blur has seams every 32 columns (Q2), so a tile needs no
@@ -1940,6 +1962,10 @@ static int build_pyramid_impl(orbfe_ctx *ctx, const uint8_t *d_src, size_t pitch
     for (int l = next_level; l < g.L; l++) {
         const int dw = g.lv[l].w, dh = g.lv[l].h;
         if (dw == 0 || dh == 0) break;
+        if (l >= 8 && dw * dh <= 4096) { // the remaining levels are tiny: one workgroup per frame does them all
+            hipLaunchKernelGGL(pyramid_tail_kernel, dim3(n_frames), dim3(256), 0, S(stream), g, ctx->d_pyr, l);
+            break;
+        }
         dim3 grid(((dw + 255) / 256) * ((dh + 3) / 4), n_frames), block(256);
         hipLaunchKernelGGL(halfsample_batch_kernel, grid, block, 0, S(stream), ctx->d_pyr, g.frame_stride,
                            g.lv[l - 1].offset, g.lv[l - 1].pitch, g.lv[l].offset, g.lv[l].pitch, dw, dh);

@@ -345,7 +345,8 @@ def _mixed_frames(w, h):
 
 
 @pytest.mark.parametrize("w,h,levels", [(640, 480, 1), (640, 480, 6), (848, 480, 6), (100, 70, 3),
-                                        (640, 480, 10), (1280, 720, 9), (636, 476, 2), (130, 258, 8)])
+                                        (640, 480, 10), (1280, 720, 9), (636, 476, 2), (130, 258, 8),
+                                        (1030, 770, 11)])  # odd width: unfused levels 1..7, then the one-launch tail
 def test_extract_reference_mode(gpu, oracle_mod, w, h, levels):
     """Reference-parity configuration: 32-px cells, FAST-12, t = 13, level-0 description."""
     torch, orbfe = gpu
