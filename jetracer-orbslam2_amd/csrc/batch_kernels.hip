@@ -597,6 +597,8 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
 constexpr int kSelThreads = 1024; // one workgroup per frame: wide, because the kernel is latency-bound
 constexpr int kSelWaves = kSelThreads / 64;
 
+template <bool SOA> // SOA: the optional cell-indexed view is wanted (a separate instantiation: its six
+                     // pointers and per-cell stores otherwise cost the common case ~1000 SGPR spill moves)
 __global__ void __launch_bounds__(kSelThreads)
 select_kernel(DeviceGeom g, const uint32_t *__restrict__ cellkey, uint4 *__restrict__ sel, uint16_t *__restrict__ cellslot,
               int32_t *__restrict__ selcount, int32_t *__restrict__ counts_out, orbfe_soa soa)
@@ -612,28 +614,66 @@ select_kernel(DeviceGeom g, const uint32_t *__restrict__ cellkey, uint4 *__restr
         s_thr = 0;          // keep score > s_thr ...
         s_quota = 0;        // ... plus the first s_quota cells with score == s_thr
     }
-    // The frame's cell keys are read twice (histogram, compaction): the first kKeyRegs trips are
-    // loaded once, unconditionally (index clamped, value masked), so that all of a thread's requests
-    // are in flight together instead of one load + wait per trip; larger grids read the rest twice.
-    constexpr int kKeyRegs = 8; // 8192 cells; 640x480 with 8-px cells has 4800
-    uint32_t kreg[kKeyRegs];
+    // A thread takes kPer consecutive cells of every chunk of kSelThreads * kPer cells.  The frame's cell
+    // keys are read twice (histogram, compaction).  Everything the histogram needs is requested up
+    // front, unconditionally (index clamped, value masked), so that all of a thread's loads are in
+    // flight together instead of one load + wait per trip: kRegChunks chunks stay in registers for the
+    // compaction, kHistChunks more (a 4K frame with 16-px cells has 32 400 cells = 8 chunks) only feed
+    // the histogram and are read again, one chunk ahead, during the compaction.
+    constexpr int kPer = 4, kChunkCells = kSelThreads * kPer;
+    constexpr int kRegChunks = 4, kHistChunks = 4;
+    const int n_chunks = (g.K + kChunkCells - 1) / kChunkCells;
+    // (one 16-byte load per thread and chunk when the frame's keys are 16-byte aligned and the four cells exist)
+    const bool vec = (((size_t)f * g.K) & 3u) == 0 && (reinterpret_cast<uintptr_t>(cellkey) & 15u) == 0; // block-uniform
+    auto load_chunk = [&](int c, uint32_t (&v)[kPer]) { // keys of chunk c, 0 past the end
+        static_assert(kPer == 4, "uint4");
+        const int k0 = c * kChunkCells + kPer * tid;
+        if (vec) {
+            const int kc = k0 + kPer <= g.K ? k0 : 0; // a group that crosses the end falls back to the masked tail below
+            const uint4 q = *reinterpret_cast<const uint4 *>(keys + kc);
+            v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w;
+            if (k0 + kPer > g.K) {
 #pragma unroll
-    for (int t = 0; t < kKeyRegs; t++) {
-        const int k = t * kSelThreads + tid;
-        const uint32_t v = keys[k < g.K ? k : g.K - 1];
-        kreg[t] = k < g.K ? v : 0u;
+                for (int j = 0; j < kPer; j++) v[j] = k0 + j < g.K ? keys[k0 + j] : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kPer; j++) {
+                const int k = k0 + j;
+                v[j] = keys[k < g.K ? k : g.K - 1];
+            }
+#pragma unroll
+            for (int j = 0; j < kPer; j++) v[j] = k0 + j < g.K ? v[j] : 0u;
+        }
+    };
+    uint32_t kreg[kRegChunks][kPer], khist[kHistChunks][kPer];
+#pragma unroll
+    for (int c = 0; c < kRegChunks; c++) load_chunk(c, kreg[c]);
+    const bool more = g.max_features > 0 && n_chunks > kRegChunks; // block-uniform
+    if (more) {
+#pragma unroll
+        for (int c = 0; c < kHistChunks; c++) load_chunk(kRegChunks + c, khist[c]);
     }
     if (g.max_features > 0) {
         for (int i = tid; i < 4096; i += kSelThreads) s_hist[i] = 0u;
         __syncthreads();
+        auto count = [&](const uint32_t (&v)[kPer]) {
 #pragma unroll
-        for (int t = 0; t < kKeyRegs; t++) {
-            const uint32_t s = kreg[t] >> 15;
-            if (s) atomicAdd(&s_hist[s], 1u);
-        }
-        for (int k = kKeyRegs * kSelThreads + tid; k < g.K; k += kSelThreads) {
-            const uint32_t s = keys[k] >> 15;
-            if (s) atomicAdd(&s_hist[s], 1u);
+            for (int j = 0; j < kPer; j++) {
+                const uint32_t sc = v[j] >> 15;
+                if (sc) atomicAdd(&s_hist[sc], 1u);
+            }
+        };
+#pragma unroll
+        for (int c = 0; c < kRegChunks; c++) count(kreg[c]);
+        if (more) {
+#pragma unroll
+            for (int c = 0; c < kHistChunks; c++) count(khist[c]);
+            for (int c = kRegChunks + kHistChunks; c < n_chunks; c++) { // still larger grids
+                uint32_t v[kPer];
+                load_chunk(c, v);
+                count(v);
+            }
         }
         __syncthreads();
         // thread t owns bins kBinsPer * t ...; `above` = how many scores lie in higher bins:
@@ -663,50 +703,114 @@ select_kernel(DeviceGeom g, const uint32_t *__restrict__ cellkey, uint4 *__restr
     __syncthreads();
     const int thr = s_thr, quota = s_quota;
 
-    int n_sel = 0, n_tie = 0;
-    for (int base = 0; base < g.K; base += kSelThreads) {
-        const int k = base + tid;
-        const bool in = k < g.K;
-        const int trip = base / kSelThreads;
-        uint32_t key = 0u;
-        if (trip < kKeyRegs) { // static after unrolling
+    // Compaction in cell order.  Kept cells = every score above the threshold plus the first `quota`
+    // cells AT the threshold, so a cell's slot is (# above before it) + min(# ties before it, quota):
+    // one block-wide prefix of a packed (above, tie) count per chunk -- DPP scan inside the wave, one
+    // barrier per chunk for the cross-wave table, which alternates between two buffers.
+    __shared__ uint32_t s_cnt[2][kSelWaves];
+    const int lane = tid & 63, wv = tid >> 6;
+    constexpr bool want_soa = SOA;
+    int n_gt = 0, n_tie = 0;
+    int ecy = (kPer * tid) / g.cells_x, ecx = kPer * tid - ecy * g.cells_x; // this thread's first cell of chunk 0
+    const int chunk_dy = kChunkCells / g.cells_x, chunk_dx = kChunkCells - chunk_dy * g.cells_x;
+    auto emit = [&](int c, const uint32_t (&key)[kPer], int par) {
+        const int k0 = c * kChunkCells + kPer * tid;
+        int ccx = ecx, ccy = ecy; // cell coordinates of k0 (no division per key: emit runs for c = 0, 1, 2, ...)
+        ecx += chunk_dx;
+        ecy += chunk_dy;
+        if (ecx >= g.cells_x) ecx -= g.cells_x, ecy++;
+        uint32_t mine = 0; // (above, ties) among this thread's cells, packed 16 : 16
 #pragma unroll
-            for (int t = 0; t < kKeyRegs; t++) key = t == trip ? kreg[t] : key;
-        } else if (in) {
-            key = keys[k];
+        for (int j = 0; j < kPer; j++) {
+            const int score = (int)(key[j] >> 15); // 0 past the end of the grid
+            mine += (score > thr ? 1u : 0u) + ((thr > 0 && score == thr) ? 0x10000u : 0u); // thr = 0: every non-empty cell
         }
-        const int score = (int)(key >> 15);
-        const bool tie = in && thr > 0 && score == thr;
-        int tie_tot;
-        const int tie_rank = block_excl_scan<kSelWaves>(tie, s_wave, &tie_tot);
-        const bool keep = in && score > 0 && (score > thr || (tie && n_tie + tie_rank < quota));
-        int keep_tot;
-        const int slot = block_excl_scan<kSelWaves>(keep, s_wave, &keep_tot);
-        int s = 0, l = 0, x = 0, y = 0;
-        const bool want_soa = soa.d_pos || soa.d_score || soa.d_level || soa.d_angle || soa.d_desc || soa.d_desc32;
-        if ((keep && sel) || (in && want_soa)) nms_decode(key, k % g.cells_x, k / g.cells_x, g.cell, &s, &l, &x, &y);
-        if (keep && sel) sel[(size_t)f * g.cap + n_sel + slot] = make_uint4((uint32_t)k, (uint32_t)x | ((uint32_t)y << 16), key, 0u);
-        if (in) cellslot[(size_t)f * g.K + k] = keep ? (uint16_t)(n_sel + slot) : (uint16_t)0xFFFFu; // cap <= 65535
-        if (in && want_soa) {
-            const size_t o = (size_t)f * g.K + k;
-            if (soa.d_pos) {
-                soa.d_pos[2 * o] = (float)x;
-                soa.d_pos[2 * o + 1] = (float)y;
-            }
-            if (soa.d_score) soa.d_score[o] = (float)s;
-            if (soa.d_level) soa.d_level[o] = l;
-            if (!keep) { // unselected / empty cells: zero angle and descriptor (Q5)
-                if (soa.d_angle) soa.d_angle[o] = 0.0f;
-                if (soa.d_desc32) soa.d_desc32[o] = 0u;
-                if (soa.d_desc) {
-                    uint32_t *d = reinterpret_cast<uint32_t *>(soa.d_desc + 32 * o);
+        const uint32_t incl = (uint32_t)wave_incl_scan_i32((int)mine);
+        if (lane == 63) s_cnt[par][wv] = incl;
+        __syncthreads();
+        uint32_t off = 0, tot = 0;
 #pragma unroll
-                    for (int j = 0; j < 8; j++) d[j] = 0u;
+        for (int u = 0; u < kSelWaves; u++) {
+            const uint32_t v = s_cnt[par][u];
+            off += u < wv ? v : 0u;
+            tot += v;
+        }
+        const uint32_t before = off + incl - mine;
+        int gt_before = n_gt + (int)(before & 0xFFFFu), tie_before = n_tie + (int)(before >> 16);
+        uint32_t slots[kPer];
+#pragma unroll
+        for (int j = 0; j < kPer; j++) {
+            const int k = k0 + j;
+            const bool in = k < g.K;
+            const int score = (int)(key[j] >> 15);
+            const bool gt = score > thr, tie = thr > 0 && score == thr;
+            const bool keep = gt || (tie && tie_before < quota);
+            const int slot = gt_before + (tie_before < quota ? tie_before : quota);
+            gt_before += gt;
+            tie_before += tie;
+            int sc = 0, l = 0, x = 0, y = 0;
+            // without the SoA view only the kept cells need their position: it is filled in below, from the
+            // compacted list (a quarter of the cells at C5), not here for every cell
+            if (want_soa && in) nms_decode(key[j], ccx, ccy, g.cell, &sc, &l, &x, &y);
+            if (++ccx == g.cells_x) ccx = 0, ccy++; // cell k + 1
+            if (keep && sel)
+                sel[(size_t)f * g.cap + slot] = make_uint4((uint32_t)k, (uint32_t)x | ((uint32_t)y << 16), key[j], 0u);
+            slots[j] = keep ? (uint32_t)slot : 0xFFFFu; // cap <= 65535
+            if (want_soa && in) {
+                const size_t o = (size_t)f * g.K + k;
+                if (soa.d_pos) {
+                    soa.d_pos[2 * o] = (float)x;
+                    soa.d_pos[2 * o + 1] = (float)y;
+                }
+                if (soa.d_score) soa.d_score[o] = (float)sc;
+                if (soa.d_level) soa.d_level[o] = l;
+                if (!keep) { // unselected / empty cells: zero angle and descriptor (Q5)
+                    if (soa.d_angle) soa.d_angle[o] = 0.0f;
+                    if (soa.d_desc32) soa.d_desc32[o] = 0u;
+                    if (soa.d_desc) {
+                        uint32_t *d = reinterpret_cast<uint32_t *>(soa.d_desc + 32 * o);
+#pragma unroll
+                        for (int jj = 0; jj < 8; jj++) d[jj] = 0u;
+                    }
                 }
             }
         }
-        n_sel += keep_tot;
-        n_tie += tie_tot;
+        uint16_t *cs = cellslot + (size_t)f * g.K + k0;
+        if (vec && k0 + kPer <= g.K) { // the four u16 slots as one 8-byte store
+            *reinterpret_cast<uint2 *>(cs) = make_uint2(slots[0] | (slots[1] << 16), slots[2] | (slots[3] << 16));
+        } else {
+#pragma unroll
+            for (int j = 0; j < kPer; j++)
+                if (k0 + j < g.K) cs[j] = (uint16_t)slots[j];
+        }
+        n_gt += (int)(tot & 0xFFFFu);
+        n_tie += (int)(tot >> 16);
+    };
+#pragma unroll
+    for (int c = 0; c < kRegChunks; c++)
+        if (c < n_chunks) emit(c, kreg[c], c & 1); // block-uniform condition
+    if (n_chunks > kRegChunks) {
+        // the rest: the next chunk's keys are requested before this chunk's prefix, so their latency is hidden
+        uint32_t cur[kPer], nxt[kPer];
+        load_chunk(kRegChunks, cur);
+        for (int c = kRegChunks; c < n_chunks; c++) {
+            load_chunk(c + 1, nxt);
+            emit(c, cur, c & 1);
+#pragma unroll
+            for (int j = 0; j < kPer; j++) cur[j] = nxt[j];
+        }
+    }
+    const int n_sel = n_gt + (n_tie < quota ? n_tie : quota);
+    if (!want_soa && sel) { // positions of the kept cells
+        __syncthreads();    // the list entries were written by other threads of this workgroup
+        for (int i = tid; i < n_sel; i += kSelThreads) {
+            uint4 *e = sel + (size_t)f * g.cap + i;
+            const uint32_t k = e->x, key = e->z;
+            const int cy = (int)k / g.cells_x;
+            int sc, l, x, y;
+            nms_decode(key, (int)k - cy * g.cells_x, cy, g.cell, &sc, &l, &x, &y);
+            e->y = (uint32_t)x | ((uint32_t)y << 16);
+        }
     }
     if (tid == 0) {
         selcount[f] = n_sel;
@@ -2057,8 +2161,12 @@ int orbfe_describe_batch(orbfe_ctx *ctx, int n_frames, orbfe_keypoint *d_records
     DeviceScope dev(ctx->cfg.device);
     if (!dev.ok) CTX_FAIL(ctx, ORBFE_ERR_HIP, "describe_batch: hipSetDevice(%d) failed", ctx->cfg.device);
     const bool patch = ctx->describe_patch == 2 || (ctx->describe_patch == 1 && (long long)n_frames * g.cap >= 32768);
-    hipLaunchKernelGGL(select_kernel, dim3(n_frames), dim3(kSelThreads), 0, S(stream), g, ctx->d_cellkey,
-                       patch ? ctx->d_sel : nullptr, ctx->d_cellslot, ctx->d_selcount, d_counts, so);
+    if (so.d_pos || so.d_score || so.d_level || so.d_angle || so.d_desc || so.d_desc32)
+        hipLaunchKernelGGL(select_kernel<true>, dim3(n_frames), dim3(kSelThreads), 0, S(stream), g, ctx->d_cellkey,
+                           patch ? ctx->d_sel : nullptr, ctx->d_cellslot, ctx->d_selcount, d_counts, so);
+    else
+        hipLaunchKernelGGL(select_kernel<false>, dim3(n_frames), dim3(kSelThreads), 0, S(stream), g, ctx->d_cellkey,
+                           patch ? ctx->d_sel : nullptr, ctx->d_cellslot, ctx->d_selcount, d_counts, so);
     if (patch) {
         if (g.angle_in_radians)
             hipLaunchKernelGGL(describe_kernel<19>, dim3((g.cap + 4 * kKpw - 1) / (4 * kKpw), n_frames), dim3(256), 0,
