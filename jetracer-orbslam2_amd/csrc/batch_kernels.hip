@@ -1655,24 +1655,33 @@ __device__ inline int bucket_coord(float v, float inv_cell, int n)
 // Thread t owns the `per` consecutive buckets [t * per, (t + 1) * per): one block-wide scan of the per-thread
 // sums instead of a pass per 256 buckets (26 -> 10 us per 128 frames of 2000 records at K = 6360).
 constexpr int kBucketThreads = 1024;
+// LDS = the K bucket counters live in LDS (K * 4 bytes of dynamic shared memory): counting, prefix and the
+// scatter cursor never leave the CU, and the bucket ends reach global memory as one coalesced pass.  With
+// the counters in global memory the prefix alone was 2 x ceil(K / 1024) dependent L2 round trips per
+// thread (17 us per 848x480 frame with 8-px cells, 5 us now).  Grids too large for LDS keep the global form.
+template <bool LDS>
 __global__ void __launch_bounds__(kBucketThreads)
 match_bucket_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *__restrict__ counts, int cap, int first,
                     int stride, int K, int cells_x, int cells_y, float inv_cell, int32_t *__restrict__ bend_all,
                     uint16_t *__restrict__ sorted_all, uint32_t *__restrict__ d32_all)
 {
+    extern __shared__ int s_bucket[];
     __shared__ int s_wave[kBucketThreads / 64];
     const int f = first + blockIdx.x * stride + 1; // the pair's curr frame
     const int n = clamp_count(counts[f], cap);
     const uint32_t *R = reinterpret_cast<const uint32_t *>(records + (size_t)f * cap);
     int32_t *bend = bend_all + (size_t)f * K;
+    int *cnt = LDS ? s_bucket : bend;
     uint16_t *sorted = sorted_all + (size_t)f * cap;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int k = tid; k < K; k += kBucketThreads) bend[k] = 0;
+    // counters written by atomics are read past this CU's L1 when they live in global memory
+    auto peek = [&](int k) { return LDS ? cnt[k] : __hip_atomic_load(&cnt[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    for (int k = tid; k < K; k += kBucketThreads) cnt[k] = 0;
     __syncthreads();
     for (int i = tid; i < n; i += kBucketThreads) {
         const int b = bucket_coord(__uint_as_float(R[13 * (size_t)i + 1]), inv_cell, cells_y) * cells_x +
                       bucket_coord(__uint_as_float(R[13 * (size_t)i]), inv_cell, cells_x);
-        atomicAdd(&bend[b], 1);
+        atomicAdd(&cnt[b], 1);
         if (d32_all) { // reference-mode matching: the 32-bit "compressed" descriptor (orb.cu:145-169) of every record
             uint32_t w[8];
 #pragma unroll
@@ -1681,19 +1690,19 @@ match_bucket_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *_
         }
     }
     __syncthreads();
-    // exclusive prefix sum over the K counts (the counts were made by L2 atomics: read them past this CU's L1)
+    // exclusive prefix sum over the K counts
     const int per = (K + kBucketThreads - 1) / kBucketThreads;
     const int k0 = tid * per, k1 = k0 + per < K ? k0 + per : K;
     int mine = 0;
-    for (int k = k0; k < k1; k++) mine += __hip_atomic_load(&bend[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int k = k0; k < k1; k++) mine += peek(k);
     const int incl = wave_incl_scan_i32(mine);
     if (lane == 63) s_wave[wv] = incl;
     __syncthreads();
     int run = incl - mine; // start of this thread's first bucket
     for (int u = 0; u < wv; u++) run += s_wave[u];
     for (int k = k0; k < k1; k++) {
-        const int c = __hip_atomic_load(&bend[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        bend[k] = run; // start of bucket k
+        const int c = peek(k);
+        cnt[k] = run; // start of bucket k
         run += c;
     }
     __syncthreads();
@@ -1701,8 +1710,24 @@ match_bucket_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *_
     for (int i = tid; i < n; i += kBucketThreads) {
         const int b = bucket_coord(__uint_as_float(R[13 * (size_t)i + 1]), inv_cell, cells_y) * cells_x +
                       bucket_coord(__uint_as_float(R[13 * (size_t)i]), inv_cell, cells_x);
-        sorted[atomicAdd(&bend[b], 1)] = (uint16_t)i;
+        sorted[atomicAdd(&cnt[b], 1)] = (uint16_t)i;
     }
+    if (LDS) {
+        __syncthreads();
+        for (int k = tid; k < K; k += kBucketThreads) bend[k] = cnt[k];
+    }
+}
+
+static void launch_match_bucket(const orbfe_keypoint *d_records, const int32_t *d_counts, int n_pairs, int cap, int first,
+                                int stride, const DeviceGeom &g, float inv_cell, int32_t *bend, uint16_t *sorted,
+                                uint32_t *d32, hipStream_t stream)
+{
+    if ((size_t)g.K * sizeof(int) <= 64 * 1024)
+        hipLaunchKernelGGL(match_bucket_kernel<true>, dim3(n_pairs), dim3(kBucketThreads), (size_t)g.K * sizeof(int), stream,
+                           d_records, d_counts, cap, first, stride, g.K, g.cells_x, g.cells_y, inv_cell, bend, sorted, d32);
+    else
+        hipLaunchKernelGGL(match_bucket_kernel<false>, dim3(n_pairs), dim3(kBucketThreads), 0, stream, d_records, d_counts,
+                           cap, first, stride, g.K, g.cells_x, g.cells_y, inv_cell, bend, sorted, d32);
 }
 
 __global__ void __launch_bounds__(256)
@@ -2234,9 +2259,8 @@ int orbfe_match_pairs(orbfe_ctx *ctx, const orbfe_keypoint *d_records, const int
         const int wc = 2 * ((window + g.cell - 1) / g.cell) + 1; // cells per window edge, at most
         if (ctx->d_bend && ctx->d_bd32 && n_frames <= ctx->cfg.max_batch && (long long)wc * wc * 4 <= (long long)g.K) {
             const float inv_cell = 1.0f / (float)g.cell;
-            hipLaunchKernelGGL(match_bucket_kernel, dim3(n_pairs), dim3(kBucketThreads), 0, S(stream), d_records, d_counts,
-                               cap, first, stride, g.K, g.cells_x, g.cells_y, inv_cell, ctx->d_bend, ctx->d_bsorted,
-                               ctx->d_bd32);
+            launch_match_bucket(d_records, d_counts, n_pairs, cap, first, stride, g, inv_cell, ctx->d_bend, ctx->d_bsorted,
+                                ctx->d_bd32, S(stream));
             hipLaunchKernelGGL(match_window_ref_kernel, grid, block, 0, S(stream), d_records, d_counts, cap, first, stride,
                                g.K, g.cells_x, g.cells_y, inv_cell, ctx->d_bend, ctx->d_bsorted, ctx->d_bd32, window,
                                max_distance, d_idx, d_dist);
@@ -2259,8 +2283,8 @@ int orbfe_match_pairs(orbfe_ctx *ctx, const orbfe_keypoint *d_records, const int
         const int wc = window >= 0 ? 2 * ((window + g.cell - 1) / g.cell) + 1 : 0; // cells per window edge, at most
         if (window >= 0 && ctx->d_bend && (long long)wc * wc * 4 <= (long long)g.K) {
             const float inv_cell = 1.0f / (float)g.cell; // exact: the cell is a power of two
-            hipLaunchKernelGGL(match_bucket_kernel, dim3(n_pairs), dim3(kBucketThreads), 0, S(stream), d_records, d_counts, cap, first,
-                               stride, g.K, g.cells_x, g.cells_y, inv_cell, ctx->d_bend, ctx->d_bsorted, (uint32_t *)nullptr);
+            launch_match_bucket(d_records, d_counts, n_pairs, cap, first, stride, g, inv_cell, ctx->d_bend, ctx->d_bsorted,
+                                (uint32_t *)nullptr, S(stream));
             hipLaunchKernelGGL(match_window_kernel, grid, block, 0, S(stream), d_records, d_counts, cap, first, stride, g.K,
                                g.cells_x, g.cells_y, inv_cell, ctx->d_bend, ctx->d_bsorted, window, max_distance, d_idx,
                                d_dist);
