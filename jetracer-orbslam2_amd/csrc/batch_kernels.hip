@@ -1730,46 +1730,143 @@ static void launch_match_bucket(const orbfe_keypoint *d_records, const int32_t *
                            cap, first, stride, g.K, g.cells_x, g.cells_y, inv_cell, bend, sorted, d32);
 }
 
+// The walk gathers: every thread reads its own ~10 candidate records, 64 different cache lines per load
+// instruction, and neighbouring queries (records are in cell order) read nearly the same candidates one
+// after the other -- the texture path's address rate, not latency or bytes, bounded it (22 us per 128
+// pairs at C3 whether the loads were issued one by one or 24 at a time).  So a workgroup of 256
+// consecutive queries first finds the cell rows its windows span, stages that contiguous piece of the
+// sorted list -- bucket ends, indices and the 40 bytes of position + descriptor per candidate -- in LDS
+// once (~400 records for 256 queries at C3 instead of 256 x 8 gathers), and the walk then reads LDS.
+// A piece that does not fit (arbitrary records can put a whole frame into a few rows) takes the
+// row-by-row kernel's path through global memory.
+constexpr int kWinStage = 512;  // candidate records a workgroup can stage (20 KB): 2 per thread
+constexpr int kWinEnds = 2048;  // bucket ends it can stage (8 KB): 8 per thread
 __global__ void __launch_bounds__(256)
 match_window_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *__restrict__ counts, int cap, int first,
                     int stride, int K, int cells_x, int cells_y, float inv_cell, const int32_t *__restrict__ bend_all,
                     const uint16_t *__restrict__ sorted_all, int window, int max_dist, int32_t *__restrict__ out_idx,
                     int32_t *__restrict__ out_dist)
 {
+    __shared__ uint32_t s_rec[kWinStage * 10];
+    __shared__ int s_end[kWinEnds];
+    __shared__ uint16_t s_j[kWinStage];
+    __shared__ int s_rmin, s_rmax;
     int pk, blk;
     xcd_remap(gridDim.x, gridDim.y, &pk, &blk); // all query blocks of a pair share one L2
     const int p = first + pk * stride;
     const int nA = clamp_count(counts[p], cap), nB = clamp_count(counts[p + 1], cap);
     const int i = blk * 256 + threadIdx.x;
-    if (i >= cap) return;
-    uint32_t best = 0xFFFFFFFFu;
-    if (i < nA && nB > 0) {
+    const bool live = i < nA && nB > 0;
+    const uint32_t *B = reinterpret_cast<const uint32_t *>(records + (size_t)(p + 1) * cap);
+    const int32_t *bend = bend_all + (size_t)(p + 1) * K;
+    const uint16_t *sorted = sorted_all + (size_t)(p + 1) * cap;
+    if (threadIdx.x == 0) s_rmin = cells_y, s_rmax = -1;
+    __syncthreads();
+    float ax = 0.0f, ay = 0.0f;
+    const float win = (float)window;
+    uint32_t a[8];
+    int bx0 = 0, bx1 = 0, by0 = 0, by1 = -1;
+    if (live) {
         const uint32_t *A = reinterpret_cast<const uint32_t *>(records + (size_t)p * cap) + 13 * (size_t)i;
-        const uint32_t *B = reinterpret_cast<const uint32_t *>(records + (size_t)(p + 1) * cap);
-        const int32_t *bend = bend_all + (size_t)(p + 1) * K;
-        const uint16_t *sorted = sorted_all + (size_t)(p + 1) * cap;
-        const float ax = __uint_as_float(A[0]), ay = __uint_as_float(A[1]), win = (float)window;
-        uint32_t a[8];
+        ax = __uint_as_float(A[0]), ay = __uint_as_float(A[1]);
 #pragma unroll
         for (int k = 0; k < 8; k++) a[k] = A[5 + k];
-        const int bx0 = bucket_coord(ax - win, inv_cell, cells_x), bx1 = bucket_coord(ax + win, inv_cell, cells_x);
-        const int by0 = bucket_coord(ay - win, inv_cell, cells_y), by1 = bucket_coord(ay + win, inv_cell, cells_y);
-        for (int by = by0; by <= by1; by++) {
-            const int g0 = by * cells_x + bx0, g1 = by * cells_x + bx1;
-            int t = g0 > 0 ? bend[g0 - 1] : 0;
-            const int e = bend[g1];
-            for (; t < e; t++) {
-                const uint32_t j = sorted[t];
-                const uint32_t *r = B + 13 * (size_t)j;
-                if (fabsf(ax - __uint_as_float(r[0])) > win || fabsf(ay - __uint_as_float(r[1])) > win) continue;
-                uint32_t dist = 0;
+        bx0 = bucket_coord(ax - win, inv_cell, cells_x), bx1 = bucket_coord(ax + win, inv_cell, cells_x);
+        by0 = bucket_coord(ay - win, inv_cell, cells_y), by1 = bucket_coord(ay + win, inv_cell, cells_y);
+    }
+    { // rows spanned by the workgroup's windows: wave minimum / maximum first, one LDS atomic per wave
+        int lo = live ? by0 : cells_y, hi = live ? by1 : -1;
 #pragma unroll
-                for (int k = 0; k < 8; k++) dist += __popc(a[k] ^ r[5 + k]);
-                const uint32_t key = (dist << 16) | j;
-                best = key < best ? key : best;
+        for (int d = 32; d >= 1; d >>= 1) {
+            lo = min(lo, __shfl_xor(lo, d));
+            hi = max(hi, __shfl_xor(hi, d));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&s_rmin, lo);
+            atomicMax(&s_rmax, hi);
+        }
+    }
+    __syncthreads();
+    const int rmin = s_rmin, rmax = s_rmax; // block-uniform from here on
+    uint32_t best = 0xFFFFFFFFu;
+    if (rmax >= rmin) {
+        const int c_lo = rmin * cells_x, c_hi = (rmax + 1) * cells_x; // cells [c_lo, c_hi)
+        const int T0 = c_lo > 0 ? bend[c_lo - 1] : 0, T1 = bend[c_hi - 1];
+        const int n = T1 - T0, n_ends = c_hi - c_lo + 1; // ends of cells c_lo - 1 .. c_hi - 1
+        if (n <= kWinStage && n_ends <= kWinEnds) {
+            // all requests first (clamped addresses), then the LDS stores: one round trip for the ends and the
+            // indices together, one more for the records
+            int ev[kWinEnds / 256];
+            uint32_t jv[kWinStage / 256];
+#pragma unroll
+            for (int u = 0; u < kWinEnds / 256; u++) {
+                const int c = c_lo - 1 + (int)threadIdx.x + 256 * u; // cell whose end this is
+                ev[u] = bend[c < 0 ? 0 : (c < K ? c : K - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < kWinStage / 256; u++) {
+                const int t = (int)threadIdx.x + 256 * u;
+                jv[u] = sorted[T0 + (t < n ? t : 0)];
+            }
+            uint32_t rv[kWinStage / 256][10];
+#pragma unroll
+            for (int u = 0; u < kWinStage / 256; u++) {
+                const uint32_t *r = B + 13 * (size_t)jv[u];
+                rv[u][0] = r[0];
+                rv[u][1] = r[1];
+#pragma unroll
+                for (int k = 0; k < 8; k++) rv[u][2 + k] = r[5 + k];
+            }
+#pragma unroll
+            for (int u = 0; u < kWinEnds / 256; u++) {
+                const int e = (int)threadIdx.x + 256 * u;
+                if (e < n_ends) s_end[e] = c_lo - 1 + e >= 0 ? ev[u] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < kWinStage / 256; u++) {
+                const int t = (int)threadIdx.x + 256 * u;
+                if (t < n) {
+                    s_j[t] = (uint16_t)jv[u];
+#pragma unroll
+                    for (int k = 0; k < 10; k++) s_rec[10 * t + k] = rv[u][k];
+                }
+            }
+            __syncthreads();
+            if (live) {
+                for (int by = by0; by <= by1; by++) {
+                    const int g0 = by * cells_x + bx0, g1 = by * cells_x + bx1;
+                    int t = s_end[g0 - c_lo] - T0; // end of cell g0 - 1
+                    const int e = s_end[g1 - c_lo + 1] - T0;
+                    for (; t < e; t++) {
+                        const uint32_t *r = s_rec + 10 * t;
+                        if (fabsf(ax - __uint_as_float(r[0])) > win || fabsf(ay - __uint_as_float(r[1])) > win) continue;
+                        uint32_t dist = 0;
+#pragma unroll
+                        for (int k = 0; k < 8; k++) dist += __popc(a[k] ^ r[2 + k]);
+                        const uint32_t key = (dist << 16) | s_j[t];
+                        best = key < best ? key : best;
+                    }
+                }
+            }
+        } else if (live) {
+            for (int by = by0; by <= by1; by++) {
+                const int g0 = by * cells_x + bx0, g1 = by * cells_x + bx1;
+                int t = g0 > 0 ? bend[g0 - 1] : 0;
+                const int e = bend[g1];
+                for (; t < e; t++) {
+                    const uint32_t j = sorted[t];
+                    const uint32_t *r = B + 13 * (size_t)j;
+                    if (fabsf(ax - __uint_as_float(r[0])) > win || fabsf(ay - __uint_as_float(r[1])) > win) continue;
+                    uint32_t dist = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) dist += __popc(a[k] ^ r[5 + k]);
+                    const uint32_t key = (dist << 16) | j;
+                    best = key < best ? key : best;
+                }
             }
         }
     }
+    if (i >= cap) return;
     const int bd = (int)(best >> 16), bj = (int)(best & 0xFFFFu);
     const bool ok = best != 0xFFFFFFFFu && bd <= max_dist;
     out_idx[(size_t)pk * cap + i] = ok ? bj : -1;
