@@ -385,13 +385,19 @@ def test_detect_stage_float_threshold_and_unaligned(gpu, oracle_mod, thr, on_dev
 
 
 # ------------------------------------------------------------------ windowed 256-bit matching through the cell index
-@pytest.mark.parametrize("w,h,cell,window,n_rec", [(640, 480, 8, 16, 1500), (640, 480, 8, 3, 2000), (320, 240, 16, 40, 300),
-                                                   (848, 480, 32, 7, 405), (640, 480, 8, 0, 1000)])
-def test_windowed_match_on_arbitrary_records(gpu, oracle_mod, w, h, cell, window, n_rec):
+@pytest.mark.parametrize("w,h,cell,window,n_rec,ordered,max_features", [
+    (640, 480, 8, 16, 1500, False, 0), (640, 480, 8, 3, 2000, False, 0), (320, 240, 16, 40, 300, False, 0),
+    (848, 480, 32, 7, 405, False, 0), (640, 480, 8, 0, 1000, False, 0),
+    # records in cell order, as the extractor writes them: a workgroup's windows span a few cell rows and the
+    # walk runs on the piece of the sorted list staged in LDS (unordered records overflow it: global path)
+    (640, 480, 8, 16, 1500, True, 0), (848, 480, 8, 16, 2000, True, 0), (640, 480, 8, 40, 900, True, 0),
+    # 129 600 cells: the bucket counters do not fit LDS (match_bucket_kernel<false>)
+    (3840, 2160, 8, 16, 3000, True, 4000), (3840, 2160, 8, 24, 2500, False, 4000)])
+def test_windowed_match_on_arbitrary_records(gpu, oracle_mod, w, h, cell, window, n_rec, ordered, max_features):
     """Records as a caller may hand them in: several per cell, non-integer positions, positions outside the
     image (bucket clamping), ragged counts.  The cell-indexed matcher must give the brute-force answer."""
     torch, orbfe = gpu
-    ctx = orbfe.Context(w, h, cell=cell, min_arc=9, max_batch=4, max_features=0)
+    ctx = orbfe.Context(w, h, cell=cell, min_arc=9, max_batch=4, max_features=max_features)
     cap = ctx.cap
     assert n_rec <= cap
     rng = np.random.default_rng(cell * 1000 + window)
@@ -410,6 +416,12 @@ def test_windowed_match_on_arbitrary_records(gpu, oracle_mod, w, h, cell, window
         rec["desc"][f, :m] = d
     rec["x"][1, :50] = rec["x"][0, :50]  # exact coincidences and window-edge cases
     rec["y"][1, :50] = rec["y"][0, :50] + window
+    if ordered:
+        for f in range(n):
+            m = cnt[f]
+            cx = np.clip(np.floor(rec["x"][f, :m] / cell), 0, (w + cell - 1) // cell - 1)
+            cy = np.clip(np.floor(rec["y"][f, :m] / cell), 0, (h + cell - 1) // cell - 1)
+            rec[f, :m] = rec[f, :m][np.lexsort((cx, cy))]
     d_rec, d_cnt = dev(torch, rec.view(np.uint8).reshape(-1)), dev(torch, cnt)
     d_idx = torch.full(((n - 1) * cap,), -7, dtype=torch.int32, device="cuda")
     d_dist = torch.full(((n - 1) * cap,), -7, dtype=torch.int32, device="cuda")
