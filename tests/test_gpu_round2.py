@@ -445,6 +445,7 @@ def test_windowed_match_on_arbitrary_records(gpu, oracle_mod, w, h, cell, window
     (848, 480, dict(levels=8, cell=8, min_arc=9, max_features=2000)),     # C3's
     (640, 480, dict(levels=1, cell=16, min_arc=12, max_features=1000)),   # C1 "1000-feature" variant: cell 16, top-1000
     (3840, 2160, dict(levels=12, cell=16, min_arc=9, max_features=8000)), # C5's
+    (3840, 2160, dict(levels=3, cell=8, min_arc=10, max_features=5000)),  # 129 600 cells: select's chunk loop past its register chunks
 ])
 def test_ext_regime_at_baseline_sizes(gpu, oracle_mod, w, h, cfg):
     from test_gpu_parity import _check_extract
