@@ -624,7 +624,7 @@ select_kernel(DeviceGeom g, const uint32_t *__restrict__ cellkey, uint4 *__restr
     constexpr int kRegChunks = 4, kHistChunks = 4;
     const int n_chunks = (g.K + kChunkCells - 1) / kChunkCells;
     // (one 16-byte load per thread and chunk when the frame's keys are 16-byte aligned and the four cells exist)
-    const bool vec = (((size_t)f * g.K) & 3u) == 0 && (reinterpret_cast<uintptr_t>(cellkey) & 15u) == 0; // block-uniform
+    const bool vec = g.K >= 4 && (((size_t)f * g.K) & 3u) == 0 && (reinterpret_cast<uintptr_t>(cellkey) & 15u) == 0; // block-uniform
     auto load_chunk = [&](int c, uint32_t (&v)[kPer]) { // keys of chunk c, 0 past the end
         static_assert(kPer == 4, "uint4");
         const int k0 = c * kChunkCells + kPer * tid;
@@ -1793,7 +1793,9 @@ match_window_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *_
         const int c_lo = rmin * cells_x, c_hi = (rmax + 1) * cells_x; // cells [c_lo, c_hi)
         const int T0 = c_lo > 0 ? bend[c_lo - 1] : 0, T1 = bend[c_hi - 1];
         const int n = T1 - T0, n_ends = c_hi - c_lo + 1; // ends of cells c_lo - 1 .. c_hi - 1
-        if (n <= kWinStage && n_ends <= kWinEnds) {
+        if (n <= 0) {
+            // no candidate in any of these rows
+        } else if (n <= kWinStage && n_ends <= kWinEnds) {
             // all requests first (clamped addresses), then the LDS stores: one round trip for the ends and the
             // indices together, one more for the records
             int ev[kWinEnds / 256];
