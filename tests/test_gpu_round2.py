@@ -385,7 +385,23 @@ def test_detect_stage_float_threshold_and_unaligned(gpu, oracle_mod, thr, on_dev
 
 
 # ------------------------------------------------------------------ windowed 256-bit matching through the cell index
-@pytest.mark.parametrize("w,h,cell,window,n_rec,ordered,max_features", [
+def _window_fuzz_cases():
+    """ORBFE_FUZZ_WINDOW=N appends N seeded random (geometry, window, count, order) cases (one-off soak runs)."""
+    import os
+    n = int(os.environ.get("ORBFE_FUZZ_WINDOW", "0"))
+    rng = np.random.default_rng(int(os.environ.get("ORBFE_FUZZ_SEED", "7")))
+    out = []
+    while len(out) < n:
+        cell = int(rng.choice([8, 16, 32]))
+        w, h = int(rng.integers(12, 60)) * 16, int(rng.integers(10, 40)) * 16
+        k = ((w + cell - 1) // cell) * ((h + cell - 1) // cell)
+        if k < 80:
+            continue
+        out.append((w, h, cell, int(rng.integers(0, 4 * cell)), int(rng.integers(60, min(k, 3000))), bool(rng.integers(0, 2)), 0))
+    return out
+
+
+@pytest.mark.parametrize("w,h,cell,window,n_rec,ordered,max_features", _window_fuzz_cases() + [
     (640, 480, 8, 16, 1500, False, 0), (640, 480, 8, 3, 2000, False, 0), (320, 240, 16, 40, 300, False, 0),
     (848, 480, 32, 7, 405, False, 0), (640, 480, 8, 0, 1000, False, 0),
     # records in cell order, as the extractor writes them: a workgroup's windows span a few cell rows and the
