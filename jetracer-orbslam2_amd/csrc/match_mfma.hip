@@ -37,12 +37,11 @@ namespace orbfe {
 // MFMAs), with v_max3_f32 at 14.7 T; the kernel reaches ~12 T.
 constexpr int kMmaS = 16384;
 constexpr float kKeyUnit = 1.0f / (2 * kMmaS); // keys are carried as (integer key) / 2S: a power of two, exact
-constexpr int kMmaRows = 128;
 constexpr int kMmaLds = 68; // floats per query row in LDS: 64 + 4 keeps writes and b128 reads conflict-free
 constexpr int kRing = 4;                 // candidate blocks in flight per wave
 constexpr int kSlotBytes = 2048 + 256;   // one block: 2 x 1 KB fragments + 16 column keys x 4 copies (a b128 read = the C tuple)
 constexpr int kRingBytes = 4 * kRing * kSlotBytes;
-constexpr int kBestBytes = kMmaRows * kMmaLds * 4;
+constexpr int kBestBytes = 128 * kMmaLds * 4; // RB = 8
 constexpr int kMmaLdsBytes = kRingBytes > kBestBytes ? kRingBytes : kBestBytes;
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -78,6 +77,10 @@ match_expand_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *_
     if (w == 0) mkey[(size_t)f * capP + i] = live ? -(float)(pop * kMmaS + i) * kKeyUnit : -1e30f;
 }
 
+// RB = query row blocks of 16 per workgroup: 8 (128 queries), or 4 when the call is so small that 128-query
+// workgroups would not even put one on every CU (one to ~15 pairs of 2000: 13 -> 10 us for a single pair,
+// 23 -> 17 us at 4800 keypoints; from 32 pairs on the larger block wins again, measured)
+template <int RB>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
 match_mfma_kernel(const uint4 *__restrict__ mexp, const float *__restrict__ mkey, const int32_t *__restrict__ counts,
                   int cap, int capP, int first, int stride, int max_dist, int32_t *__restrict__ out_idx,
@@ -92,6 +95,7 @@ match_mfma_kernel(const uint4 *__restrict__ mexp, const float *__restrict__ mkey
     const int nA = clamp_count(counts[p], cap), nB = clamp_count(counts[p + 1], cap);
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform: block indices stay in SGPRs
+    constexpr int kMmaRows = 16 * RB;
     const int row0 = blk * kMmaRows;
     const uint4 *__restrict__ Ea = mexp + (size_t)p * capP * 8;
     const uint4 *__restrict__ Eb = mexp + (size_t)(p + 1) * capP * 8;
@@ -99,9 +103,9 @@ match_mfma_kernel(const uint4 *__restrict__ mexp, const float *__restrict__ mkey
     const bool active = row0 < nA && nB > 0; // block-uniform
 
     if (active) {
-        v8i a[8][2];
+        v8i a[RB][2];
 #pragma unroll
-        for (int m = 0; m < 8; m++) {
+        for (int m = 0; m < RB; m++) {
             const int ab = (row0 >> 4) + m;
             const bool in = ab * 16 < capP;
 #pragma unroll
@@ -110,9 +114,9 @@ match_mfma_kernel(const uint4 *__restrict__ mexp, const float *__restrict__ mkey
                 a[m][ks] = (v8i){(int)q.x, (int)q.y, (int)q.z, (int)q.w, 0, 0, 0, 0};
             }
         }
-        v4f best[8];
+        v4f best[RB];
 #pragma unroll
-        for (int m = 0; m < 8; m++) best[m] = (v4f){-3e38f, -3e38f, -3e38f, -3e38f};
+        for (int m = 0; m < RB; m++) best[m] = (v4f){-3e38f, -3e38f, -3e38f, -3e38f};
         const int nBb = (nB + 15) >> 4;
         // This wave's candidate blocks wv, wv + 4, ... stream through a ring of kRing LDS slots
         // filled by LDS-DMA (global_load_lds: no VGPRs, nothing the register allocator could
@@ -163,7 +167,7 @@ match_mfma_kernel(const uint4 *__restrict__ mexp, const float *__restrict__ mkey
             const v8i d0 = (v8i){(int)p0.x, (int)p0.y, (int)p0.z, (int)p0.w, 0, 0, 0, 0};
             const v8i d1 = (v8i){(int)p1.x, (int)p1.y, (int)p1.z, (int)p1.w, 0, 0, 0, 0};
 #pragma unroll
-            for (int m = 0; m < 8; m++) {
+            for (int m = 0; m < RB; m++) {
                 // cbsz = blgp = 4: e2m1 operands; scale arguments 0, 0 select the unscaled instruction
                 v4f acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m][0], b0, cv, 4, 4, 0, 0, 0, 0);
                 v4f acd = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m][0], d0, dv, 4, 4, 0, 0, 0, 0);
@@ -192,7 +196,7 @@ match_mfma_kernel(const uint4 *__restrict__ mexp, const float *__restrict__ mkey
         __syncthreads();                                  // every wave is done with its ring: s_best reuses it
         // C/D layout: lane holds rows 4 * (lane >> 4) + r of each 16-row fragment, column lane & 15
 #pragma unroll
-        for (int m = 0; m < 8; m++)
+        for (int m = 0; m < RB; m++)
 #pragma unroll
             for (int r = 0; r < 4; r++)
                 s_best[(m * 16 + 4 * (lane >> 4) + r) * kMmaLds + wv * 16 + (lane & 15)] = best[m][r];
@@ -200,7 +204,7 @@ match_mfma_kernel(const uint4 *__restrict__ mexp, const float *__restrict__ mkey
     __syncthreads();
     const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
     float v = -3e38f;
-    if (active) {
+    if (active && row < kMmaRows) {
         const float4 *src = reinterpret_cast<const float4 *>(s_best + row * kMmaLds + half * 32);
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -210,7 +214,7 @@ match_mfma_kernel(const uint4 *__restrict__ mexp, const float *__restrict__ mkey
     }
     v = fmaxf(v, __shfl_xor(v, 1));
     const int i = row0 + row;
-    if (half == 0 && i < cap) {
+    if (half == 0 && row < kMmaRows && i < cap) {
         bool ok = active && i < nA && v > -1e29f;
         int bj = -1, bd = -1;
         if (ok) {
@@ -233,8 +237,12 @@ void launch_match_mfma(const orbfe_keypoint *d_records, const int32_t *d_counts,
     static_assert(kMmaS == kMmaMaxKeypoints, "key packing");
     hipLaunchKernelGGL(match_expand_kernel, dim3((capP * 8 + 255) / 256, n_frames), dim3(256), 0, stream, d_records,
                        d_counts, cap, capP, mexp, mkey);
-    hipLaunchKernelGGL(match_mfma_kernel, dim3((capP + kMmaRows - 1) / kMmaRows, n_pairs), dim3(256), 0, stream,
-                       mexp, mkey, d_counts, cap, capP, first, stride, max_dist, d_idx, d_dist);
+    if ((long long)n_pairs * ((capP + 127) / 128) >= 256) // at least one 128-query workgroup per CU
+        hipLaunchKernelGGL(match_mfma_kernel<8>, dim3((capP + 127) / 128, n_pairs), dim3(256), 0, stream, mexp, mkey,
+                           d_counts, cap, capP, first, stride, max_dist, d_idx, d_dist);
+    else
+        hipLaunchKernelGGL(match_mfma_kernel<4>, dim3((capP + 63) / 64, n_pairs), dim3(256), 0, stream, mexp, mkey,
+                           d_counts, cap, capP, first, stride, max_dist, d_idx, d_dist);
 }
 
 } // namespace orbfe
