@@ -471,6 +471,9 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
     // px = 3 / px = 68 of every row).
     // `inner` tiles (no image border inside the score tile) skip the per-pixel range tests.
     const bool inner = x0 >= 4 && x0 + kTileW < W - 3 && y0 >= 4 && y0 + kTileH < H - 3;
+    static_assert(kTrips * 4 <= 32, "one flag word per lane");
+    uint32_t allflags = 0, ebase[kTrips]; // 4 candidate flags per trip; (r << 7) | 4 q of the trip's dword group
+#pragma unroll
     for (int trip = 0; trip < kTrips; trip++) {
         uint32_t flags = 0;
         int r, q;
@@ -511,17 +514,22 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
             const uint32_t Ed = __builtin_amdgcn_alignbyte(Rr, C, 3); // bytes x+3
             flags = compass4(C, Wd, Ed, Nd, Sd, t2, need3) & mask;
         }
-        // wave-level compaction: inclusive scan of the per-lane candidate counts
-        const int cnt = __popc(flags);
+        allflags |= flags << (4 * trip);
+        ebase[trip] = (uint32_t)((r << 7) | (4 * q));
+    }
+    // wave-level compaction, ONCE for all trips: a lane's candidates take consecutive slots starting at
+    // the exclusive prefix of the per-lane counts (one DPP scan per tile and wave instead of one per trip:
+    // the scan, not the test, was a third of this phase's instructions)
+    {
+        const int cnt = __popc(allflags);
         const int incl = wave_incl_scan_i32(cnt);
-        const int total = __builtin_amdgcn_readlane(incl, 63);
-        if (total) {
-            int slot = n1 + incl - cnt;
+        n1 = __builtin_amdgcn_readlane(incl, 63);
+        int slot = incl - cnt;
+#pragma unroll
+        for (int trip = 0; trip < kTrips; trip++)
 #pragma unroll
             for (int i = 0; i < 4; i++)
-                if (flags >> i & 1u) q1[slot++] = (uint16_t)((r << 7) | (4 * q + i));
-            n1 += total;
-        }
+                if (allflags >> (4 * trip + i) & 1u) q1[slot++] = (uint16_t)(ebase[trip] + i);
     }
     // (no block barrier: each wave consumes only its own queue; LDS ops of a wave are in order)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
