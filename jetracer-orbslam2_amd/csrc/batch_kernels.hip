@@ -903,7 +903,7 @@ static std::vector<int8_t> make_moment_weights(int R)
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-template <int R>
+template <int R, bool SOA>
 __global__ void __launch_bounds__(256)
 describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__restrict__ sel,
                 const int32_t *__restrict__ selcount, const uint4 *__restrict__ momw,
@@ -1089,7 +1089,7 @@ describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__re
                 rec[5 + 2 * k] = (uint32_t)d[k];
                 rec[6 + 2 * k] = (uint32_t)(d[k] >> 32);
             }
-            if (soa.d_angle || soa.d_desc32 || soa.d_desc) {
+            if (SOA && (soa.d_angle || soa.d_desc32 || soa.d_desc)) { // (SOA: its own instantiation, as in select_kernel)
                 const size_t o = (size_t)f * g.K + kcell[it];
                 if (soa.d_angle) soa.d_angle[o] = angle;
                 if (soa.d_desc32) soa.d_desc32[o] = orb_compress(d);
@@ -1161,7 +1161,7 @@ static std::vector<int8_t> make_tile_moment_weights()
     return w;
 }
 
-template <int R>
+template <int R, bool SOA>
 __global__ void __launch_bounds__(256)
 describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32_t *__restrict__ cellkey,
                      const uint16_t *__restrict__ cellslot, const uint4 *__restrict__ momw, int tiles_x,
@@ -1347,7 +1347,7 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
                 rec[5 + 2 * k] = (uint32_t)d[k];
                 rec[6 + 2 * k] = (uint32_t)(d[k] >> 32);
             }
-            if (soa.d_angle || soa.d_desc32 || soa.d_desc) {
+            if (SOA && (soa.d_angle || soa.d_desc32 || soa.d_desc)) { // (SOA: its own instantiation, as in select_kernel)
                 const int cell = (y / g.cell) * g.cells_x + x / g.cell;
                 const size_t o = (size_t)f * g.K + cell;
                 if (soa.d_angle) soa.d_angle[o] = angle;
@@ -2299,22 +2299,23 @@ int orbfe_describe_batch(orbfe_ctx *ctx, int n_frames, orbfe_keypoint *d_records
     else
         hipLaunchKernelGGL(select_kernel<false>, dim3(n_frames), dim3(kSelThreads), 0, S(stream), g, ctx->d_cellkey,
                            patch ? ctx->d_sel : nullptr, ctx->d_cellslot, ctx->d_selcount, d_counts, so);
+    const bool want_soa = so.d_pos || so.d_score || so.d_level || so.d_angle || so.d_desc || so.d_desc32;
+#define ORBFE_DESCRIBE_LAUNCH(KERNEL, GRID, ...)                                                                    \
+    do {                                                                                                            \
+        if (g.angle_in_radians && want_soa) hipLaunchKernelGGL((KERNEL<19, true>), GRID, dim3(256), 0, S(stream), __VA_ARGS__);  \
+        else if (g.angle_in_radians) hipLaunchKernelGGL((KERNEL<19, false>), GRID, dim3(256), 0, S(stream), __VA_ARGS__);        \
+        else if (want_soa) hipLaunchKernelGGL((KERNEL<15, true>), GRID, dim3(256), 0, S(stream), __VA_ARGS__);                   \
+        else hipLaunchKernelGGL((KERNEL<15, false>), GRID, dim3(256), 0, S(stream), __VA_ARGS__);                                \
+    } while (0)
     if (patch) {
-        if (g.angle_in_radians)
-            hipLaunchKernelGGL(describe_kernel<19>, dim3((g.cap + 4 * kKpw - 1) / (4 * kKpw), n_frames), dim3(256), 0,
-                               S(stream), g, ctx->d_pyr, ctx->d_sel, ctx->d_selcount, ctx->d_momw, d_records, so);
-        else
-            hipLaunchKernelGGL(describe_kernel<15>, dim3((g.cap + 4 * kKpw - 1) / (4 * kKpw), n_frames), dim3(256), 0,
-                               S(stream), g, ctx->d_pyr, ctx->d_sel, ctx->d_selcount, ctx->d_momw, d_records, so);
+        ORBFE_DESCRIBE_LAUNCH(describe_kernel, dim3((g.cap + 4 * kKpw - 1) / (4 * kKpw), n_frames), g, ctx->d_pyr, ctx->d_sel,
+                              ctx->d_selcount, ctx->d_momw, d_records, so);
     } else {
         const int tiles_x = (g.W + kDTile - 1) / kDTile, tiles_y = (g.H + kDTile - 1) / kDTile;
-        if (g.angle_in_radians)
-            hipLaunchKernelGGL(describe_tile_kernel<19>, dim3(tiles_x * tiles_y, n_frames), dim3(256), 0, S(stream), g,
-                               ctx->d_pyr, ctx->d_cellkey, ctx->d_cellslot, ctx->d_momw_tile, tiles_x, d_records, so);
-        else
-            hipLaunchKernelGGL(describe_tile_kernel<15>, dim3(tiles_x * tiles_y, n_frames), dim3(256), 0, S(stream), g,
-                               ctx->d_pyr, ctx->d_cellkey, ctx->d_cellslot, ctx->d_momw_tile, tiles_x, d_records, so);
+        ORBFE_DESCRIBE_LAUNCH(describe_tile_kernel, dim3(tiles_x * tiles_y, n_frames), g, ctx->d_pyr, ctx->d_cellkey,
+                              ctx->d_cellslot, ctx->d_momw_tile, tiles_x, d_records, so);
     }
+#undef ORBFE_DESCRIBE_LAUNCH
     CTX_LAUNCH_CHECK(ctx, "describe_batch");
     return ORBFE_OK;
 }
