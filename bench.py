@@ -523,6 +523,11 @@ def main():
                 ach = valu_counts[k] * 64 / t / 1e12
                 e["valu"] = {"bound": "valu", "unit": "Tlane-op/s", "achieved": ach, "peak": VALU_PEAK_TLANEOPS,
                              "frac": ach / VALU_PEAK_TLANEOPS, "wave_instructions_per_launch": valu_counts[k]}
+                # share of SIMD cycles with a VALU instruction executing (SQ_ACTIVE_INST_VALU, same PMC pass): the
+                # lane-op fraction prices every instruction at full rate, the mix here is largely half-rate
+                busy = prof.get("valu_pipe_busy", {}).get(k)
+                if busy is not None:
+                    e["valu"]["pipe_busy"] = busy
             per_stage[k] = e
         if mfma_match and "match" in per_stage:
             # the 256-bit matcher runs on the matrix cores: 2 x 256 flop per pair on e2m1 operands,

@@ -40,9 +40,15 @@ try:
     allj = json.load(open(out))
 except Exception:
     allj = {}
+# fraction of SIMD cycles with a VALU instruction executing: SQ_ACTIVE_INST_VALU counts quad-cycles summed over
+# the 1024 SIMDs, GRBM_GUI_ACTIVE the cycles of the 8 XCDs
+act = {s: sum(per_launch(q, p, lambda v: v.get("SQ_ACTIVE_INST_VALU", {}).get("avg", 0.0)) for p in ks) for s, ks in STAGES.items()}
+cyc = {s: sum(per_launch(q, p, lambda v: v.get("GRBM_GUI_ACTIVE", {}).get("avg", 0.0)) for p in ks) / 8.0 for s, ks in STAGES.items()}
 stages["valu_wave_instructions"] = valu
+stages["valu_pipe_busy"] = {s: (act[s] * 4.0 / 1024.0 / cyc[s] if cyc[s] else None) for s in STAGES}
 allj[mode] = stages
 allj["_note"] = ("per stage launch (256 frames): HBM-side bytes from rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE "
-                 "passes (reads doubled per the gfx950 correction) and VALU wave-instructions from an SQ_INSTS_VALU pass")
+                 "passes (reads doubled per the gfx950 correction), VALU wave-instructions (SQ_INSTS_VALU) and the fraction of "
+                 "SIMD cycles with a VALU instruction executing (SQ_ACTIVE_INST_VALU x 4 / 1024 / cycles) from SQ passes")
 json.dump(allj, open(out, "w"), indent=1, sort_keys=True)
 print(json.dumps(stages))
