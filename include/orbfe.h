@@ -14,7 +14,10 @@
  *     (checkCudaErrors / exit(1), src/cuda_common.h:69-77); orbfe_last_error() gives text.
  *   - no global mutable state: the rBRIEF pattern is a compile-time constant (the
  *     reference uploads it with loadPattern(), src/cuda/orb.cu:218-225) and the FAST LUT
- *     is a caller buffer as in the reference.  A context is thread-compatible, not
+ *     is a caller buffer as in the reference, read as an opaque table by every call that
+ *     takes it -- nothing is remembered about how, where or for which arc it was built.
+ *     (The only writable static storage in the library is the thread-local text buffer
+ *     behind orbfe_last_error(NULL).)  A context is thread-compatible, not
  *     thread-safe: ONE context = ONE host thread + ONE stream at a time (its pyramid, cell
  *     keys and matcher scratch are single copies), as the reference runs one buildStream
  *     thread per stream (src/SlamGpuPipeline/SlamGpuPipeline.cpp:43-50).  Calls leave the
@@ -32,7 +35,7 @@
 extern "C" {
 #endif
 
-#define ORBFE_VERSION 1
+#define ORBFE_VERSION 2 /* 2: orbfe_config gained descriptor_level (appended) */
 
 enum {
     ORBFE_OK = 0,
@@ -102,7 +105,11 @@ int orbfe_fast_calc_corner_response(int image_width, int image_height, int image
 int orbfe_grid_nms(const orbfe_pyramid_level *levels, int n_levels, float *d_pos,
                    float *d_score, int *d_level, orbfe_stream_t stream);
 
-/* detect, src/cuda/fast.cuh:42-48 = corner response on every level, then grid_nms. */
+/* detect, src/cuda/fast.cuh:42-48 = corner response on every level, then grid_nms.
+ * d_corner_lut is the opaque 65536-byte table of the reference: a corner is what the
+ * reference's prechecks (fast.cu:98-124) let through AND lut[dark] | lut[bright] accepts,
+ * for any table contents (one built by orbfe_fast_calculate_lut, copied, or filled by the
+ * caller).  levels[i].response may be NULL (the maps are then not written). */
 int orbfe_detect(const orbfe_pyramid_level *levels, int n_levels,
                  const unsigned char *d_corner_lut, float threshold, float *d_pos,
                  float *d_score, int *d_level, orbfe_stream_t stream);
@@ -202,6 +209,12 @@ typedef struct orbfe_config {
     int32_t angle_in_radians;  /* 0 = reference (radians used as degrees); 1 = fixed       */
     int32_t max_batch;         /* frames per orbfe_extract call the context is sized for   */
     int32_t device;            /* HIP device ordinal                                       */
+    int32_t descriptor_level;  /* 0 = reference (orientation + descriptor always sample    */
+                               /* level 0 at the level-0 position, buildStream.cpp:442-460,*/
+                               /* quirk Q10); 1 = EXT iv: they sample the pyramid level    */
+                               /* that won the cell, at position / 2^level, with that      */
+                               /* level's size in every bound and guard band (scale-aware  */
+                               /* ORB).  Records keep level-0 coordinates either way.      */
 } orbfe_config;
 
 /* 52-byte keypoint record, little endian. */

@@ -18,6 +18,10 @@
  * wait for the outstanding collectives, orbfe_dist_sync() blocks the host.
  *
  * There is NO CPU fallback: without a HIP device / RCCL every call returns an error status.
+ *
+ * VERIFICATION STATUS: with one rank (world = 1) every entry point is exercised on hardware by the GPU
+ * tests; the code under `world > 1` (grouped ncclSend / ncclRecv, the all-reduce) has NOT executed on any
+ * multi-GPU node available to the build -- see DESIGN.md section 5.
  */
 #ifndef ORBFE_DIST_H
 #define ORBFE_DIST_H
@@ -67,6 +71,15 @@ int orbfe_dist_shard_range(int n_total, int rank, int world, int *begin, int *en
 int orbfe_dist_gather_keypoints(orbfe_dist *d, const orbfe_keypoint *d_records, const int32_t *d_counts,
                                 int n_frames, int cap, orbfe_keypoint *d_all_records,
                                 int32_t *d_all_counts, int root, int exact, orbfe_stream_t stream);
+
+/* Root side of the exact-length form: where does frame f of rank r start?  Writes world * n_frames record
+ * indices into d_all_records (int64): offsets[r * n_frames + f] = r * n_frames * cap + sum(counts_r[0 .. f-1]),
+ * from the gathered d_all_counts (counts clamped to [0, cap] as everywhere).  A kernel on `stream` (which must
+ * already wait for the gather: orbfe_dist_wait); nothing touches the host.  With these and d_all_counts a consumer
+ * walks the dense layout without re-deriving it; for the fixed-stride form the offsets are simply
+ * (r * n_frames + f) * cap and no call is needed. */
+int orbfe_dist_exact_offsets(orbfe_dist *d, const int32_t *d_all_counts, int n_frames, int cap,
+                             int64_t *d_offsets, orbfe_stream_t stream);
 
 /* All-reduce(MAX) of n unsigned 32-bit cell keys in place (tile-sharded detection of one frame;
  * keys are < 2^27).  Ordered after `stream`, runs on the communicator's stream; follow with

@@ -283,9 +283,12 @@ constexpr int kScW = kTileW + 2, kScH = kTileH + 2; // 66 x 66 score tile (1-px 
 constexpr int kScPitch = kScW + 2;                   // 68
 constexpr int kMaxLdsCells = (kTileW / 4) * (kTileH / 4);
 
-// candidate flags of 4 horizontally adjacent pixels -> bit i = pixel i may be a corner
-__device__ inline uint32_t compass4(uint32_t C, uint32_t Wd, uint32_t Ed, uint32_t Nd, uint32_t Sd,
-                                    uint32_t t2, bool need3)
+// candidate flags of 4 horizontally adjacent pixels -> bit i = pixel i may be a corner.
+// MODE 0: arcs 9..11, MODE 1: arc >= 12 (closed forms, below); MODE 2: the reference's own opposite-pair
+// prechecks (fast.cu:98-124), literally -- the ring test runs iff (W or E is not similar to the centre) and
+// (N or S is not similar): the only form that is valid for an ARBITRARY corner table (stage API).
+template <int MODE>
+__device__ inline uint32_t compass4(uint32_t C, uint32_t Wd, uint32_t Ed, uint32_t Nd, uint32_t Sd, uint32_t t2)
 {
     uint32_t out = 0;
 #pragma unroll
@@ -294,19 +297,29 @@ __device__ inline uint32_t compass4(uint32_t C, uint32_t Wd, uint32_t Ed, uint32
         auto lanes = [h](uint32_t x) { return U2(h ? __builtin_amdgcn_perm(0u, x, 0x0C030C01u) : (x & 0x00FF00FFu)); };
         const us2 c = lanes(C), w = lanes(Wd), e = lanes(Ed), n = lanes(Nd), s = lanes(Sd);
         const us2 hi = c + U2(t2), lo = ssub(c, U2(t2));
-        const us2 a = pmax(n, s), b = pmin(n, s), cc = pmax(e, w), d = pmin(e, w);
-        const us2 m1 = pmin(a, cc), m2 = pmax(b, d);
-        // arc >= 12 (need3): 3 of the 4 compass pixels lie in the arc, so the 3rd largest must be brighter
-        // or the 3rd smallest (= 2nd largest) darker.  arc 9..11: the arc leaves at most 7 contiguous ring
-        // pixels out, so it holds one pixel of EVERY opposite pair: max(N,S) and max(E,W) both brighter
-        // (m1), or min(N,S) and min(E,W) both darker (m2) -- tighter than "2 of 4" and two ops less
-        us2 bv = m1, dv = m2;
-        if (need3) {
-            bv = pmin(m1, m2);
-            dv = pmax(m1, m2);
+        uint32_t f;
+        if (MODE == 2) {
+            // not similar: v > c + t or v < c - t (lo saturates at 0, where "darker" is impossible)
+            auto nonsim = [&](us2 v) { return U1(ssub(v, hi)) | U1(ssub(lo, v)); };
+            uint32_t fh = nonsim(w) | nonsim(e), fv = nonsim(n) | nonsim(s);
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(fh) : "v"(fh), "v"(0x00010001u));
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(fv) : "v"(fv), "v"(0x00010001u));
+            f = fh & fv;
+        } else {
+            const us2 a = pmax(n, s), b = pmin(n, s), cc = pmax(e, w), d = pmin(e, w);
+            const us2 m1 = pmin(a, cc), m2 = pmax(b, d);
+            // arc >= 12 (MODE 1): 3 of the 4 compass pixels lie in the arc, so the 3rd largest must be brighter
+            // or the 3rd smallest (= 2nd largest) darker.  arc 9..11: the arc leaves at most 7 contiguous ring
+            // pixels out, so it holds one pixel of EVERY opposite pair: max(N,S) and max(E,W) both brighter
+            // (m1), or min(N,S) and min(E,W) both darker (m2) -- tighter than "2 of 4" and two ops less
+            us2 bv = m1, dv = m2;
+            if (MODE == 1) {
+                bv = pmin(m1, m2);
+                dv = pmax(m1, m2);
+            }
+            f = U1(ssub(bv, hi)) | U1(ssub(lo, dv)); // 16-bit lane != 0 <=> candidate
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(f) : "v"(f), "v"(0x00010001u)); // lanes -> 0 / 1
         }
-        uint32_t f = U1(ssub(bv, hi)) | U1(ssub(lo, dv)); // 16-bit lane != 0 <=> candidate
-        asm("v_pk_min_u16 %0, %1, %2" : "=v"(f) : "v"(f), "v"(0x00010001u)); // lanes -> 0 / 1
         out |= f << h; // h = 0: bits 0 and 16 (pixels 0, 2); h = 1: bits 1 and 17 (pixels 1, 3)
     }
     out = (out | (out >> 14)) & 0xFu; // bit i = pixel i
@@ -314,7 +327,9 @@ __device__ inline uint32_t compass4(uint32_t C, uint32_t Wd, uint32_t Ed, uint32
 }
 
 // FAST score (0 = not a corner) of the pixel at LDS byte pointer p, two ring pixels per op.
-__device__ inline int fast_score_packed(const uint8_t *p, uint32_t t2, int arc)
+// arc 9..12: the arc test in closed form; arc 0: the caller's corner table decides (lut[dark] | lut[bright],
+// fast.cu:230-231), whatever it holds.
+__device__ inline int fast_score_packed(const uint8_t *p, uint32_t t2, int arc, const uint8_t *__restrict__ lut)
 {
     const uint32_t c = p[0];
     const us2 c2 = U2(c | (c << 16));
@@ -341,7 +356,11 @@ __device__ inline int fast_score_packed(const uint8_t *p, uint32_t t2, int arc)
     }
     const uint32_t ub = U1(mb), ud = U1(md);
     const uint32_t bright = (ub & 0xFFu) | ((ub >> 16) << 8), dark = (ud & 0xFFu) | ((ud >> 16) << 8);
-    if (!(orbfe_has_arc(bright, arc) | orbfe_has_arc(dark, arc))) return 0;
+    if (arc == 0) {
+        if (!(lut[bright] | lut[dark])) return 0;
+    } else if (!(orbfe_has_arc(bright, arc) | orbfe_has_arc(dark, arc))) {
+        return 0;
+    }
     const uint32_t xb = U1(sb), xd = U1(sd);
     const int rb = (int)((xb & 0xFFFFu) + (xb >> 16)), rd = (int)((xd & 0xFFFFu) + (xd >> 16));
     return rb > rd ? rb : rd;
@@ -355,11 +374,14 @@ struct StageTiles {
     int tiles_x[8];
     float *resp[8];    // response map of level l (may be null) ...
     int resp_pitch[8]; // ... and its pitch in floats
+    const uint8_t *lut; // the caller's 65536-byte corner table (ARC = 0)
 };
 
 // ARC = the minimum arc length as a compile-time constant (9..12): the compass test's variant and the
 // closed-form arc test then carry no run-time selects (8 fewer instructions per compass trip, ~10 per
-// ring-test batch).
+// ring-test batch).  ARC = 0 (the stage API): no arc is assumed at all -- the pre-test is the reference's own
+// (fast.cu:98-124) and every candidate looks its two masks up in the caller's table, so the result is the
+// reference's for ANY table contents (fast.cuh:25-26, :42-48 treat it as opaque).
 template <bool STAGE, int ARC>
 __global__ void __launch_bounds__(256)
 detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc *__restrict__ tiles,
@@ -463,7 +485,7 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
     // ---- B: compass pre-test, 4 pixels per lane; score-tile row r <-> image y0 - 1 + r,
     //         pixel-tile column px <-> image x0 - 4 + px
     const uint32_t t2 = (uint32_t)g.threshold * 0x00010001u;
-    constexpr bool need3 = ARC >= 12;
+    constexpr int kCompass = ARC == 0 ? 2 : (ARC >= 12 ? 1 : 0);
     int n1 = 0; // wave-uniform fill level of q1
     // Task = one dword group q (pixels px = 4q .. 4q+3) of score row r.  The first kMainTrips
     // trips cover the tile proper (rows 1..kTileH, groups 1..16, 16 rows per trip: no division in
@@ -512,7 +534,7 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
             const uint32_t Nd = row[q - 3 * kPxDw], Sd = row[q + 3 * kPxDw];
             const uint32_t Wd = __builtin_amdgcn_alignbyte(C, L, 1);  // bytes x-3 of the 4 pixels
             const uint32_t Ed = __builtin_amdgcn_alignbyte(Rr, C, 3); // bytes x+3
-            flags = compass4(C, Wd, Ed, Nd, Sd, t2, need3) & mask;
+            flags = compass4<kCompass>(C, Wd, Ed, Nd, Sd, t2) & mask;
         }
         allflags |= flags << (4 * trip);
         ebase[trip] = (uint32_t)((r << 7) | (4 * q));
@@ -544,7 +566,7 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
         if (i < n1) {
             e = q1[i];
             const int r = e >> 7, px = e & 127;
-            const int sc = fast_score_packed(s_px + (r + 3) * kPxW + px, t2, ARC);
+            const int sc = fast_score_packed(s_px + (r + 3) * kPxW + px, t2, ARC, st.lut);
             if (sc) {
                 s_sc[r * kScPitch + px - 3] = (uint16_t)sc;
                 pos = r >= 1 && r <= kTileH && px >= 4 && px < 4 + kTileW;
@@ -903,7 +925,9 @@ static std::vector<int8_t> make_moment_weights(int R)
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-template <int R, bool SOA>
+// DL = EXT iv, descriptor_level: a keypoint's patch comes from the pyramid level that won its cell, at
+// position >> level, with that level's size in every bound (its own instantiation: level 0 stays as it was).
+template <int R, bool SOA, bool DL>
 __global__ void __launch_bounds__(256)
 describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__restrict__ sel,
                 const int32_t *__restrict__ selcount, const uint4 *__restrict__ momw,
@@ -923,8 +947,7 @@ describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__re
     const int slot0 = (blk * 4 + wv) * kKpw; // wave-uniform
     if (slot0 >= n) return;
     const int nk = n - slot0 < kKpw ? n - slot0 : kKpw;
-    const uint8_t *img = pyr + (size_t)f * g.frame_stride + g.lv[0].offset;
-    const int P = g.lv[0].pitch;
+    const uint8_t *fbase = pyr + (size_t)f * g.frame_stride;
     const uint4 *fsel = sel + (size_t)f * g.cap + slot0;
     uint8_t *wpatch = s_patch + wv * (kKpw * kPatchBytes); // this wave's kKpw patches
     // weight fragments of the moment MFMAs and this lane's four rBRIEF pattern rows (the same for
@@ -936,15 +959,17 @@ describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__re
 #pragma unroll
     for (int r = 0; r < 4; r++) pat[r] = reinterpret_cast<const float4 *>(c_pattern_f)[64 * r + lane];
 
-    int kx[kKpw], ky[kKpw], kax[kKpw], m10[kKpw], m01[kKpw];
+    int kx[kKpw], ky[kKpw], kax[kKpw], m10[kKpw], m01[kKpw], klv[kKpw];
     uint32_t kcell[kKpw], kkey[kKpw];
     // chunk c of a patch = (row c / kChunksRow, 16-byte column c % kChunksRow); trip t stages chunks
-    // 64 t + lane.  Their image offsets relative to the patch origin, once per wave.
-    uint32_t voff[G::kTrips];
+    // 64 t + lane.  Their (row, byte column) relative to the patch origin, once per wave; the image offset
+    // is row * pitch + column with the pitch of the keypoint's level.
+    int vrow[G::kTrips], vcol[G::kTrips];
 #pragma unroll
     for (int t = 0; t < G::kTrips; t++) {
-        const int c = 64 * t + lane, r = c / G::kChunksRow;
-        voff[t] = (uint32_t)(__mul24(r, P) + G::kChunk * (c - r * G::kChunksRow));
+        const int c = 64 * t + lane;
+        vrow[t] = c / G::kChunksRow;
+        vcol[t] = G::kChunk * (c - vrow[t] * G::kChunksRow);
     }
     // the wave's selection entries: uniform addresses = scalar loads, all four issued before the first
     // use (behind the uniform `it >= nk` test each would be followed by its own wait)
@@ -954,13 +979,17 @@ describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__re
     // ---- pass 1: stage + moments
 #pragma unroll
     for (int it = 0; it < kKpw; it++) {
-        kx[it] = ky[it] = kax[it] = m10[it] = m01[it] = 0;
+        kx[it] = ky[it] = kax[it] = m10[it] = m01[it] = klv[it] = 0;
         kcell[it] = kkey[it] = 0;
         if (it >= nk) continue; // uniform
         const uint4 sr = srs[it];
         kcell[it] = sr.x;
         kkey[it] = sr.z;
-        const int x = (int)(sr.y & 0xFFFFu), y = (int)(sr.y >> 16);
+        const int l = DL ? 7 - (int)((sr.z >> 12) & 7u) : 0; // uniform: the level that won the cell
+        klv[it] = l;
+        const int Wl = g.lv[l].w, Hl = g.lv[l].h, P = g.lv[l].pitch;
+        const uint8_t *img = fbase + g.lv[l].offset;
+        const int x = (int)(sr.y & 0xFFFFu) >> l, y = (int)(sr.y >> 16) >> l; // level coordinates (exact: pos = coord << l)
         kx[it] = x;
         ky[it] = y;
         const int oy = y - R;
@@ -971,8 +1000,8 @@ describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__re
         // disc meets no excluded pixel (row <= 0, row >= H, column <= 0, column >= W: orb.cu:98,112,
         // 119).  Bytes outside the disc or the image width then carry zero weight and are never
         // sampled by the descriptor (17 / 19-px guard band), so their values do not matter.
-        const bool inner = oy >= 0 && oy + kRows <= g.H && ax >= 0 && ax + kPitch <= P && y > 15 && y + 15 < g.H &&
-                           x > 15 && x + 15 < g.W; // uniform
+        const bool inner = oy >= 0 && oy + kRows <= Hl && ax >= 0 && ax + kPitch <= P && y > 15 && y + 15 < Hl &&
+                           x > 15 && x + 15 < Wl; // uniform
         if (inner) {
             // LDS-DMA: global_load_lds_dwordx4 writes lane L's 16 bytes to (uniform LDS base) + 16 L
             // with no VGPR round trip and no ds_write.  Address = scalar patch origin + the lane's
@@ -985,7 +1014,7 @@ describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__re
                 // from emitting the kernel's stub)
                 static_assert(G::kChunk == 16, "DMA size literal below");
                 if (64 * (t + 1) <= G::kChunks || 64 * t + lane < G::kChunks)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pb + voff[t]),
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pb + (uint32_t)(__mul24(vrow[t], P) + vcol[t])),
                                                      (__attribute__((address_space(3))) void *)(sp + 1024 * t), 16, 0, 0);
             }
         } else {
@@ -994,10 +1023,10 @@ describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__re
                 const int r = i / (kPitch / 4), q = i - r * (kPitch / 4);
                 const int gy = oy + r, gx = ax + 4 * q;
                 uint32_t v = 0;
-                if (gy > 0 && gy < g.H && gx >= 0 && gx < g.W) {
+                if (gy > 0 && gy < Hl && gx >= 0 && gx < Wl) {
                     v = *reinterpret_cast<const uint32_t *>(img + (uint32_t)(__mul24(gy, P) + gx));
                     if (gx == 0) v &= 0xFFFFFF00u;
-                    const int nv = g.W - gx; // valid bytes in this dword
+                    const int nv = Wl - gx; // valid bytes in this dword
                     if (nv < 4) v &= (1u << (8 * nv)) - 1u;
                 }
                 reinterpret_cast<uint32_t *>(sp)[i] = v;
@@ -1069,18 +1098,18 @@ describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__re
         const float angle = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(langle), it));
         const float a = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(la), it));
         const float b = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(lb), it));
-        const int x = kx[it], y = ky[it];
+        const int x = kx[it], y = ky[it], l = klv[it];
         // samples are addressed relative to s_patch: the keypoint's byte offset in it is one constant
         uint64_t d[4] = {0, 0, 0, 0};
-        if (!orb_border_zero(x, y, g.W, g.H, g.angle_in_radians))
+        if (!orb_border_zero(x, y, g.lv[l].w, g.lv[l].h, g.angle_in_radians))
             orb_describe_lds<G::kPitch>(s_patch, (wv * kKpw + it) * kPatchBytes + R * G::kPitch + x - kax[it], a, b, pat, d);
 
         // every value is wave-uniform: lane 0 stores the 13 dwords of the record
         if (lane == 0) {
             const int score = (int)(kkey[it] >> 15), level = 7 - (int)((kkey[it] >> 12) & 7u);
             uint32_t *rec = reinterpret_cast<uint32_t *>(records + (size_t)f * g.cap + slot0 + it);
-            rec[0] = __float_as_uint((float)x);
-            rec[1] = __float_as_uint((float)y);
+            rec[0] = __float_as_uint((float)(x << l)); // records keep level-0 coordinates
+            rec[1] = __float_as_uint((float)(y << l));
             rec[2] = __float_as_uint((float)score);
             rec[3] = (uint32_t)level;
             rec[4] = __float_as_uint(angle);
@@ -1161,29 +1190,43 @@ static std::vector<int8_t> make_tile_moment_weights()
     return w;
 }
 
-template <int R, bool SOA>
+// DL = EXT iv, descriptor_level: one workgroup = one 64x64 tile of ONE PYRAMID LEVEL (the detection tile list)
+// and the keypoints that level won inside it, sampled at position >> level.  A level-l tile spans
+// (64 / (cell >> l))^2 cells, up to 4096, so the keypoint list is gathered in passes of at most 64 (wave 0
+// appends whole 64-cell groups while they fit); with DL = false there is exactly one group and one pass.
+template <int R, bool SOA, bool DL>
 __global__ void __launch_bounds__(256)
 describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32_t *__restrict__ cellkey,
                      const uint16_t *__restrict__ cellslot, const uint4 *__restrict__ momw, int tiles_x,
-                     orbfe_keypoint *__restrict__ records, orbfe_soa soa)
+                     const TileDesc *__restrict__ tiles, orbfe_keypoint *__restrict__ records, orbfe_soa soa)
 {
     using G = TileGeom<R>;
     constexpr int P = G::kPitch;
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[G::kBytes + G::kPad];
-    __shared__ uint32_t s_kxy[64], s_kkey[64], s_kslot[64]; // the tile's keypoints: x | y << 16, key, record slot
+    __shared__ uint32_t s_kxy[64], s_kkey[64], s_kslot[64]; // the pass's keypoints: x | y << 16 (level coordinates), key, record slot
     __shared__ int s_mom[128];                               // their moments: m10, m01
     __shared__ float s_ang[64], s_cos[64], s_sin[64];        // angle and steering (cos, sin)
-    __shared__ int s_nkp;
+    __shared__ int s_nkp, s_cursor;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int f, tile;
     xcd_remap(gridDim.x, gridDim.y, &f, &tile);
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    int l = 0, tx, ty;
+    if (DL) {
+        const TileDesc td = tiles[tile];
+        l = td.level;
+        tx = td.tx;
+        ty = td.ty;
+    } else {
+        ty = tile / tiles_x;
+        tx = tile - ty * tiles_x;
+    }
+    const int W = g.lv[l].w, H = g.lv[l].h; // the sampled level (l = 0 unless DL)
     const int x0 = tx * kDTile, y0 = ty * kDTile;
     const int ox = x0 - G::kHaloX, oy = y0 - R; // image position of tile byte (0, 0)
-    const uint8_t *img = pyr + (size_t)f * g.frame_stride + g.lv[0].offset;
-    const int IP = g.lv[0].pitch;
+    const uint8_t *img = pyr + (size_t)f * g.frame_stride + g.lv[l].offset;
+    const int IP = g.lv[l].pitch;
 
     // ---- stage the tile: chunk q = (row q / kChunksRow, 16-byte column q % kChunksRow) lands at LDS byte 16 q.
     //      Addresses are clamped into the image (rows) and the padded pitch (columns): every load is
@@ -1194,174 +1237,198 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
         if (256 * (t + 1) <= G::kChunks || q < G::kChunks) {
             const int r = q / G::kChunksRow, cc = q - r * G::kChunksRow;
             int gy = oy + r, gx = ox + 16 * cc;
-            gy = gy < 0 ? 0 : (gy >= g.H ? g.H - 1 : gy);
+            gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
             gx = gx < 0 ? 0 : (gx > IP - 16 ? IP - 16 : gx);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(img + (uint32_t)(__mul24(gy, IP) + gx)),
                                              (__attribute__((address_space(3))) void *)(s_tile + 16 * (256 * t + 64 * wv)), 16, 0, 0);
         }
     }
-    if (tid < 128) s_mom[tid] = 0;
-    // ---- the tile's keypoints (wave 0, while the DMAs fly): one lane per cell of the tile
-    const int n = kDTile / g.cell; // cells per tile edge: 8, 4, 2 or 1
-    if (wv == 0) {
-        const int cxl = lane & (n - 1), cyl = lane >> ilog2(n);
-        const int cx = tx * n + cxl, cy = ty * n + cyl;
-        const bool valid = lane < n * n && cx < g.cells_x && cy < g.cells_y;
-        const int k = cy * g.cells_x + cx;
-        uint32_t slot = 0xFFFFu, key = 0;
-        if (valid) {
-            slot = cellslot[(size_t)f * g.K + k];
-            key = cellkey[(size_t)f * g.K + k];
-        }
-        const bool keep = valid && slot != 0xFFFFu;
-        const uint64_t m = __ballot(keep);
-        if (keep) {
-            int sc, lv, x, y;
-            nms_decode(key, cx, cy, g.cell, &sc, &lv, &x, &y);
-            const int pos = (int)__popcll(m & ((1ull << lane) - 1ull));
-            s_kxy[pos] = (uint32_t)x | ((uint32_t)y << 16);
-            s_kkey[pos] = key;
-            s_kslot[pos] = slot; // the cell index is recomputed from (x, y) where the SoA view needs it
-        }
-        if (lane == 0) s_nkp = (int)__popcll(m);
-    }
-    // LDS-DMA data is ordered only behind the issuing wave's vmcnt; then the barrier publishes it
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const int nkp = s_nkp;
-    if (nkp == 0) return; // uniform
-    // ---- border tiles: zero what the moments exclude / what lies outside the image
-    // ---- border tiles: zero what the moments exclude / what lies outside the image: rows gy <= 0 and
-    //      gy >= H, columns gx <= 0 and gx >= W (only the strips concerned are touched)
-    if (ox <= 0 || ox + P > g.W || oy <= 0 || oy + G::kRows > g.H) { // uniform
-        uint32_t *t32 = reinterpret_cast<uint32_t *>(s_tile);
-        constexpr int PD = P / 4;
-        const int rtop = oy <= 0 ? 1 - oy : 0;                           // rows [0, rtop) lie at gy <= 0
-        const int rbot = g.H - oy < G::kRows ? g.H - oy : G::kRows;      // rows [rbot, kRows) at gy >= H
-        for (int i = tid; i < rtop * PD; i += 256) t32[i] = 0u;
-        for (int i = rbot * PD + tid; i < G::kRows * PD; i += 256) t32[i] = 0u;
-        // column strips of the rows in between: `lanes` threads per row, one dword each per pass
-        auto strip = [&](int d0, int nd, int first_keep, int last_keep) { // dwords [d0, d0 + nd); bytes outside [first_keep, last_keep) go
-            const int sh = nd <= 8 ? 3 : 5, d = d0 + (tid & ((1 << sh) - 1));
-            if (d >= d0 + nd) return;
-            uint32_t keep = 0xFFFFFFFFu;
-            const int lo = first_keep - 4 * d, hi = last_keep - 4 * d; // byte j of this dword kept iff lo <= j < hi
-            if (lo >= 4 || hi <= 0) keep = 0u;
-            else {
-                if (lo > 0) keep &= 0xFFFFFFFFu << (8 * lo);
-                if (hi < 4) keep &= (1u << (8 * hi)) - 1u;
-            }
-            for (int r = rtop + (tid >> sh); r < rbot; r += 256 >> sh) t32[r * PD + d] &= keep;
-        };
-        if (ox <= 0) strip(0, (1 - ox + 3) / 4, 1 - ox, P);              // gx <= 0  <=> byte < 1 - ox
-        if (ox + P > g.W) strip((g.W - ox) / 4, PD - (g.W - ox) / 4, 0, g.W - ox); // gx >= W <=> byte >= W - ox
-        __syncthreads();
-    }
-    // weight fragments of the moment MFMAs and this lane's four rBRIEF pattern rows
+    // cells of this tile: edge cl = cell >> l pixels of the level, n per tile edge (1 .. 64), in groups of 64
+    const int cl = g.cell >> l;
+    const int n = kDTile / cl, ln = ilog2(n);
+    const int ngroups = DL ? (n * n + 63) >> 6 : 1;
+    // weight fragments of the moment MFMAs and this lane's four rBRIEF pattern rows (loaded in the first pass)
     uint4 bw[G::kMom];
-#pragma unroll
-    for (int ks = 0; ks < G::kMom; ks++) bw[ks] = momw[ks * 64 + lane];
     float4 pat[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) pat[r] = reinterpret_cast<const float4 *>(c_pattern_f)[64 * r + lane];
-
-    // ---- phase A: moments of groups of kKpw keypoints on the matrix cores -> s_m10 / s_m01
-    for (int grp = wv; grp * kKpw < nkp; grp += 4) { // uniform
-        const int k0 = grp * kKpw;
-        const int nk = nkp - k0 < kKpw ? nkp - k0 : kKpw;
-        // A fragment of lane (chunk c, row = keypoint + 4 * slice) = 16 bytes of disc-box row
-        // 8 ks + 2 slice + (c >> 1), columns 16 (c & 1) .. + 15, at the keypoint's own byte position
-        const int row = lane & 15, c = lane >> 4;
-        const int j = k0 + ((row & 3) < nk ? (row & 3) : nk - 1);
-        const uint32_t xy = s_kxy[j];
-        const int kb = ((int)(xy >> 16) - 15 - oy) * P + (int)(xy & 0xFFFFu) - 15 - ox;
-        // 16 bytes from an arbitrary byte address = 5 aligned dwords realigned by v_alignbyte: byte-misaligned
-        // wide LDS reads are served one lane at a time on gfx950 (26.8 ns per wave-instruction against < 3 ns
-        // aligned, tools/lds_unaligned_rate.hip)
-        const int abyte = kb + (2 * (row >> 2) + (c >> 1)) * P + 16 * (c & 1);
-        const uint32_t *a32 = reinterpret_cast<const uint32_t *>(s_tile + (abyte & ~3));
-        const uint32_t ash = (uint32_t)abyte & 3u;
-        u32x4 av[G::kMom];
-#pragma unroll
-        for (int ks = 0; ks < G::kMom; ks++) {
-            const uint32_t *q = a32 + ks * 2 * P; // 8 rows further
-            const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
-            av[ks].x = __builtin_amdgcn_alignbyte(d1, d0, ash);
-            av[ks].y = __builtin_amdgcn_alignbyte(d2, d1, ash);
-            av[ks].z = __builtin_amdgcn_alignbyte(d3, d2, ash);
-            av[ks].w = __builtin_amdgcn_alignbyte(d4, d3, ash);
-        }
-        v4i acc = {0, 0, 0, 0};
-#pragma unroll
-        for (int ks = 0; ks < G::kMom; ks++) {
-            const uint4 bv = bw[ks];
-            const v4i a = {(int)(av[ks].x ^ 0x80808080u), (int)(av[ks].y ^ 0x80808080u), (int)(av[ks].z ^ 0x80808080u),
-                           (int)(av[ks].w ^ 0x80808080u)};
-            const v4i b = {(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w};
-            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc, 0, 0, 0);
-        }
-        // D[row][col] sits in lane 16 * (row / 4) + col, register row % 4: keypoint `it`, slice s, weights xy
-        // -> register `it` of lane 18 s + xy.  The four slices meet in LDS: lanes 18 s + xy add register `it`
-        // into s_mom[2 (k0 + it) + xy] (4 adders per word, LDS atomics: integer, order-free)
-        const int sl = lane >> 4, cxy = (lane & 15) - 2 * sl; // this lane's slice and column offset inside it
-        if (cxy == 0 || cxy == 1) {
-#pragma unroll
-            for (int it = 0; it < kKpw; it++)
-                if (it < nk) atomicAdd(&s_mom[2 * (k0 + it) + cxy], acc[it]);
-        }
-    }
-    __syncthreads();
-    // ---- phase B: one lane per keypoint: atan2f and the steering cos / sin, ONCE per tile
-    if (wv == 0 && lane < nkp) {
-        const float ang = orbfe_atan2f((float)s_mom[2 * lane + 1], (float)s_mom[2 * lane]);
-        float ca, sb;
-        orb_steer(ang, g.angle_in_radians, &ca, &sb);
-        s_ang[lane] = ang;
-        s_cos[lane] = ca;
-        s_sin[lane] = sb;
-    }
-    __syncthreads();
-    // ---- phase C: descriptors + records, keypoints dealt round-robin to the waves
-    for (int j = wv; j < nkp; j += 4) { // uniform
-        const uint32_t xy = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_kxy[j]);
-        const uint32_t key = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_kkey[j]);
-        const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_kslot[j]);
-        const float angle = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_ang[j])));
-        const float a = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_cos[j])));
-        const float b = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_sin[j])));
-        const int x = (int)(xy & 0xFFFFu), y = (int)(xy >> 16);
-        uint64_t d[4] = {0, 0, 0, 0};
-        if (!orb_border_zero(x, y, g.W, g.H, g.angle_in_radians))
-            orb_describe_lds<P>(s_tile, (y - oy) * P + x - ox, a, b, pat, d);
-        // every value is wave-uniform: lane 0 stores the 13 dwords of the record
-        if (lane == 0) {
-            const int score = (int)(key >> 15), level = 7 - (int)((key >> 12) & 7u);
-            uint32_t *rec = reinterpret_cast<uint32_t *>(records + (size_t)f * g.cap + slot);
-            rec[0] = __float_as_uint((float)x);
-            rec[1] = __float_as_uint((float)y);
-            rec[2] = __float_as_uint((float)score);
-            rec[3] = (uint32_t)level;
-            rec[4] = __float_as_uint(angle);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                rec[5 + 2 * k] = (uint32_t)d[k];
-                rec[6 + 2 * k] = (uint32_t)(d[k] >> 32);
+    int cursor = 0; // next cell group (uniform)
+    bool first = true;
+    for (;;) {
+        if (tid < 128) s_mom[tid] = 0;
+        // ---- the pass's keypoints (wave 0; in the first pass while the DMAs fly): one lane per cell of a group
+        if (wv == 0) {
+            int cnt = 0;
+            do {
+                const int idx = 64 * cursor + lane;
+                const int cxl = idx & (n - 1), cyl = idx >> ln;
+                const int cx = tx * n + cxl, cy = ty * n + cyl;
+                const bool valid = idx < n * n && cx < g.cells_x && cy < g.cells_y;
+                const int k = cy * g.cells_x + cx;
+                uint32_t slot = 0xFFFFu, key = 0;
+                if (valid) {
+                    slot = cellslot[(size_t)f * g.K + k];
+                    key = cellkey[(size_t)f * g.K + k];
+                }
+                const bool keep = valid && slot != 0xFFFFu && (!DL || 7 - (int)((key >> 12) & 7u) == l);
+                const uint64_t m = __ballot(keep);
+                const int c = (int)__popcll(m);
+                if (DL && cnt + c > 64) break; // this group waits for the next pass (an empty list takes any group)
+                if (keep) {
+                    int sc, lv, x, y;
+                    nms_decode(key, cx, cy, g.cell, &sc, &lv, &x, &y);
+                    const int pos = cnt + (int)__popcll(m & ((1ull << lane) - 1ull));
+                    s_kxy[pos] = (uint32_t)(x >> l) | ((uint32_t)(y >> l) << 16);
+                    s_kkey[pos] = key;
+                    s_kslot[pos] = slot; // the cell index is recomputed from (x, y) where the SoA view needs it
+                }
+                cnt += c;
+                cursor++;
+            } while (DL && cursor < ngroups);
+            if (lane == 0) {
+                s_nkp = cnt;
+                s_cursor = cursor;
             }
-            if (SOA && (soa.d_angle || soa.d_desc32 || soa.d_desc)) { // (SOA: its own instantiation, as in select_kernel)
-                const int cell = (y / g.cell) * g.cells_x + x / g.cell;
-                const size_t o = (size_t)f * g.K + cell;
-                if (soa.d_angle) soa.d_angle[o] = angle;
-                if (soa.d_desc32) soa.d_desc32[o] = orb_compress(d);
-                if (soa.d_desc) {
-                    uint32_t *sd = reinterpret_cast<uint32_t *>(soa.d_desc + 32 * o);
+        }
+        // LDS-DMA data is ordered only behind the issuing wave's vmcnt; then the barrier publishes it
+        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int nkp = s_nkp;
+        if (DL) cursor = s_cursor;
+        if (nkp == 0) return; // uniform: no (further) keypoint in this tile
+        if (first) {
+            // ---- border tiles: zero what the moments exclude / what lies outside the image: rows gy <= 0 and
+            //      gy >= H, columns gx <= 0 and gx >= W (only the strips concerned are touched)
+            if (ox <= 0 || ox + P > W || oy <= 0 || oy + G::kRows > H) { // uniform
+                uint32_t *t32 = reinterpret_cast<uint32_t *>(s_tile);
+                constexpr int PD = P / 4;
+                const int rtop = oy <= 0 ? 1 - oy : 0;                       // rows [0, rtop) lie at gy <= 0
+                const int rbot = H - oy < G::kRows ? H - oy : G::kRows;      // rows [rbot, kRows) at gy >= H
+                for (int i = tid; i < rtop * PD; i += 256) t32[i] = 0u;
+                for (int i = rbot * PD + tid; i < G::kRows * PD; i += 256) t32[i] = 0u;
+                // column strips of the rows in between: `lanes` threads per row, one dword each per pass
+                auto strip = [&](int d0, int nd, int first_keep, int last_keep) { // dwords [d0, d0 + nd); bytes outside [first_keep, last_keep) go
+                    const int sh = nd <= 8 ? 3 : 5, d = d0 + (tid & ((1 << sh) - 1));
+                    if (d >= d0 + nd) return;
+                    uint32_t keep = 0xFFFFFFFFu;
+                    const int lo = first_keep - 4 * d, hi = last_keep - 4 * d; // byte j of this dword kept iff lo <= j < hi
+                    if (lo >= 4 || hi <= 0) keep = 0u;
+                    else {
+                        if (lo > 0) keep &= 0xFFFFFFFFu << (8 * lo);
+                        if (hi < 4) keep &= (1u << (8 * hi)) - 1u;
+                    }
+                    for (int r = rtop + (tid >> sh); r < rbot; r += 256 >> sh) t32[r * PD + d] &= keep;
+                };
+                if (ox <= 0) strip(0, (1 - ox + 3) / 4, 1 - ox, P);          // gx <= 0  <=> byte < 1 - ox
+                if (ox + P > W) strip((W - ox) / 4, PD - (W - ox) / 4, 0, W - ox); // gx >= W <=> byte >= W - ox
+                __syncthreads();
+            }
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        sd[2 * k] = (uint32_t)d[k];
-                        sd[2 * k + 1] = (uint32_t)(d[k] >> 32);
+            for (int ks = 0; ks < G::kMom; ks++) bw[ks] = momw[ks * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; r++) pat[r] = reinterpret_cast<const float4 *>(c_pattern_f)[64 * r + lane];
+            first = false;
+        }
+
+        // ---- phase A: moments of groups of kKpw keypoints on the matrix cores -> s_m10 / s_m01
+        for (int grp = wv; grp * kKpw < nkp; grp += 4) { // uniform
+            const int k0 = grp * kKpw;
+            const int nk = nkp - k0 < kKpw ? nkp - k0 : kKpw;
+            // A fragment of lane (chunk c, row = keypoint + 4 * slice) = 16 bytes of disc-box row
+            // 8 ks + 2 slice + (c >> 1), columns 16 (c & 1) .. + 15, at the keypoint's own byte position
+            const int row = lane & 15, c = lane >> 4;
+            const int j = k0 + ((row & 3) < nk ? (row & 3) : nk - 1);
+            const uint32_t xy = s_kxy[j];
+            const int kb = ((int)(xy >> 16) - 15 - oy) * P + (int)(xy & 0xFFFFu) - 15 - ox;
+            // 16 bytes from an arbitrary byte address = 5 aligned dwords realigned by v_alignbyte: byte-misaligned
+            // wide LDS reads are served one lane at a time on gfx950 (26.8 ns per wave-instruction against < 3 ns
+            // aligned, tools/lds_unaligned_rate.hip)
+            const int abyte = kb + (2 * (row >> 2) + (c >> 1)) * P + 16 * (c & 1);
+            const uint32_t *a32 = reinterpret_cast<const uint32_t *>(s_tile + (abyte & ~3));
+            const uint32_t ash = (uint32_t)abyte & 3u;
+            u32x4 av[G::kMom];
+#pragma unroll
+            for (int ks = 0; ks < G::kMom; ks++) {
+                const uint32_t *q = a32 + ks * 2 * P; // 8 rows further
+                const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+                av[ks].x = __builtin_amdgcn_alignbyte(d1, d0, ash);
+                av[ks].y = __builtin_amdgcn_alignbyte(d2, d1, ash);
+                av[ks].z = __builtin_amdgcn_alignbyte(d3, d2, ash);
+                av[ks].w = __builtin_amdgcn_alignbyte(d4, d3, ash);
+            }
+            v4i acc = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < G::kMom; ks++) {
+                const uint4 bv = bw[ks];
+                const v4i a = {(int)(av[ks].x ^ 0x80808080u), (int)(av[ks].y ^ 0x80808080u), (int)(av[ks].z ^ 0x80808080u),
+                               (int)(av[ks].w ^ 0x80808080u)};
+                const v4i b = {(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w};
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc, 0, 0, 0);
+            }
+            // D[row][col] sits in lane 16 * (row / 4) + col, register row % 4: keypoint `it`, slice s, weights xy
+            // -> register `it` of lane 18 s + xy.  The four slices meet in LDS: lanes 18 s + xy add register `it`
+            // into s_mom[2 (k0 + it) + xy] (4 adders per word, LDS atomics: integer, order-free)
+            const int sl = lane >> 4, cxy = (lane & 15) - 2 * sl; // this lane's slice and column offset inside it
+            if (cxy == 0 || cxy == 1) {
+#pragma unroll
+                for (int it = 0; it < kKpw; it++)
+                    if (it < nk) atomicAdd(&s_mom[2 * (k0 + it) + cxy], acc[it]);
+            }
+        }
+        __syncthreads();
+        // ---- phase B: one lane per keypoint: atan2f and the steering cos / sin, ONCE per pass
+        if (wv == 0 && lane < nkp) {
+            const float ang = orbfe_atan2f((float)s_mom[2 * lane + 1], (float)s_mom[2 * lane]);
+            float ca, sb;
+            orb_steer(ang, g.angle_in_radians, &ca, &sb);
+            s_ang[lane] = ang;
+            s_cos[lane] = ca;
+            s_sin[lane] = sb;
+        }
+        __syncthreads();
+        // ---- phase C: descriptors + records, keypoints dealt round-robin to the waves
+        for (int j = wv; j < nkp; j += 4) { // uniform
+            const uint32_t xy = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_kxy[j]);
+            const uint32_t key = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_kkey[j]);
+            const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_kslot[j]);
+            const float angle = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_ang[j])));
+            const float a = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_cos[j])));
+            const float b = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_sin[j])));
+            const int x = (int)(xy & 0xFFFFu), y = (int)(xy >> 16);
+            uint64_t d[4] = {0, 0, 0, 0};
+            if (!orb_border_zero(x, y, W, H, g.angle_in_radians))
+                orb_describe_lds<P>(s_tile, (y - oy) * P + x - ox, a, b, pat, d);
+            // every value is wave-uniform: lane 0 stores the 13 dwords of the record
+            if (lane == 0) {
+                const int score = (int)(key >> 15), level = 7 - (int)((key >> 12) & 7u);
+                const int X = x << l, Y = y << l; // records keep level-0 coordinates
+                uint32_t *rec = reinterpret_cast<uint32_t *>(records + (size_t)f * g.cap + slot);
+                rec[0] = __float_as_uint((float)X);
+                rec[1] = __float_as_uint((float)Y);
+                rec[2] = __float_as_uint((float)score);
+                rec[3] = (uint32_t)level;
+                rec[4] = __float_as_uint(angle);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    rec[5 + 2 * k] = (uint32_t)d[k];
+                    rec[6 + 2 * k] = (uint32_t)(d[k] >> 32);
+                }
+                if (SOA && (soa.d_angle || soa.d_desc32 || soa.d_desc)) { // (SOA: its own instantiation, as in select_kernel)
+                    const int cell = (Y / g.cell) * g.cells_x + X / g.cell;
+                    const size_t o = (size_t)f * g.K + cell;
+                    if (soa.d_angle) soa.d_angle[o] = angle;
+                    if (soa.d_desc32) soa.d_desc32[o] = orb_compress(d);
+                    if (soa.d_desc) {
+                        uint32_t *sd = reinterpret_cast<uint32_t *>(soa.d_desc + 32 * o);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            sd[2 * k] = (uint32_t)d[k];
+                            sd[2 * k + 1] = (uint32_t)(d[k] >> 32);
+                        }
                     }
                 }
             }
         }
+        if (!DL || cursor >= ngroups) break;
+        __syncthreads(); // every wave is done with this pass's lists before the next gather overwrites them
     }
 }
 
@@ -1572,15 +1639,15 @@ match_batch_256_kernel(const Desc8 *__restrict__ mdesc, const float2 *__restrict
     }
 }
 
-template <bool STAGE>
 static void launch_detect_tiles(const DeviceGeom &g, dim3 grid, hipStream_t stream, const uint8_t *pyr, const TileDesc *tiles,
-                                uint32_t *cellkey, int tile_first, int tile_step, const StageTiles &st)
+                                uint32_t *cellkey, int tile_first, int tile_step)
 {
+    const StageTiles st{};
     switch (g.arc) { // validated to 9..12 where the geometry is built
-    case 9: hipLaunchKernelGGL((detect_tile_kernel<STAGE, 9>), grid, dim3(256), 0, stream, g, pyr, tiles, cellkey, tile_first, tile_step, st); break;
-    case 10: hipLaunchKernelGGL((detect_tile_kernel<STAGE, 10>), grid, dim3(256), 0, stream, g, pyr, tiles, cellkey, tile_first, tile_step, st); break;
-    case 11: hipLaunchKernelGGL((detect_tile_kernel<STAGE, 11>), grid, dim3(256), 0, stream, g, pyr, tiles, cellkey, tile_first, tile_step, st); break;
-    default: hipLaunchKernelGGL((detect_tile_kernel<STAGE, 12>), grid, dim3(256), 0, stream, g, pyr, tiles, cellkey, tile_first, tile_step, st); break;
+    case 9: hipLaunchKernelGGL((detect_tile_kernel<false, 9>), grid, dim3(256), 0, stream, g, pyr, tiles, cellkey, tile_first, tile_step, st); break;
+    case 10: hipLaunchKernelGGL((detect_tile_kernel<false, 10>), grid, dim3(256), 0, stream, g, pyr, tiles, cellkey, tile_first, tile_step, st); break;
+    case 11: hipLaunchKernelGGL((detect_tile_kernel<false, 11>), grid, dim3(256), 0, stream, g, pyr, tiles, cellkey, tile_first, tile_step, st); break;
+    default: hipLaunchKernelGGL((detect_tile_kernel<false, 12>), grid, dim3(256), 0, stream, g, pyr, tiles, cellkey, tile_first, tile_step, st); break;
     }
 }
 
@@ -1600,8 +1667,8 @@ __global__ void stage_decode_kernel(int K, int cells_x, int cell0, float *__rest
     d_level[k] = l;
 }
 
-int launch_detect_stage(const orbfe_pyramid_level *lv, int n_levels, int threshold, int arc, float *d_pos, float *d_score,
-                        int *d_level, hipStream_t stream)
+int launch_detect_stage(const orbfe_pyramid_level *lv, int n_levels, int threshold, const uint8_t *d_lut, float *d_pos,
+                        float *d_score, int *d_level, hipStream_t stream)
 {
     DeviceGeom g;
     memset(&g, 0, sizeof(g));
@@ -1614,9 +1681,10 @@ int launch_detect_stage(const orbfe_pyramid_level *lv, int n_levels, int thresho
     g.K = g.cells_x * g.cells_y;
     g.cap = g.K;
     g.threshold = threshold;
-    g.arc = arc;
+    g.arc = 0; // unknown and not needed: the table decides
     StageTiles st;
     memset(&st, 0, sizeof(st));
+    st.lut = d_lut;
     int n_tiles = 0;
     for (int l = 0; l < n_levels; l++) {
         g.lv[l].w = (int)lv[l].image_width;
@@ -1638,7 +1706,8 @@ int launch_detect_stage(const orbfe_pyramid_level *lv, int n_levels, int thresho
     uint32_t *keys = reinterpret_cast<uint32_t *>(d_score); // 4 bytes per cell: the key, then (decode) the score
     if (hipMemsetAsync(keys, 0, (size_t)g.K * sizeof(uint32_t), stream) != hipSuccess) return ORBFE_ERR_HIP;
     if (n_tiles > 0)
-        launch_detect_tiles<true>(g, dim3(n_tiles, 1), stream, lv[0].image, nullptr, keys, 0, 1, st);
+        hipLaunchKernelGGL((detect_tile_kernel<true, 0>), dim3(n_tiles, 1), dim3(256), 0, stream, g, lv[0].image,
+                           (const TileDesc *)nullptr, keys, 0, 1, st);
     hipLaunchKernelGGL(stage_decode_kernel, dim3((g.K + 255) / 256), dim3(256), 0, stream, g.K, g.cells_x, g.cell, d_score,
                        d_pos, d_level);
     return hipGetLastError() == hipSuccess ? ORBFE_OK : ORBFE_ERR_HIP;
@@ -1730,7 +1799,8 @@ static void launch_match_bucket(const orbfe_keypoint *d_records, const int32_t *
                                 int stride, const DeviceGeom &g, float inv_cell, int32_t *bend, uint16_t *sorted,
                                 uint32_t *d32, hipStream_t stream)
 {
-    if ((size_t)g.K * sizeof(int) <= 64 * 1024)
+    // dynamic K * 4 bytes + the kernel's static s_wave must fit the 64 KiB a workgroup may ask for by default
+    if ((size_t)g.K * sizeof(int) + (kBucketThreads / 64) * sizeof(int) <= 64 * 1024)
         hipLaunchKernelGGL(match_bucket_kernel<true>, dim3(n_pairs), dim3(kBucketThreads), (size_t)g.K * sizeof(int), stream,
                            d_records, d_counts, cap, first, stride, g.K, g.cells_x, g.cells_y, inv_cell, bend, sorted, d32);
     else
@@ -2000,6 +2070,7 @@ void orbfe_default_config(orbfe_config *cfg, int width, int height)
     cfg->angle_in_radians = 0;
     cfg->max_batch = 1;
     cfg->device = 0;
+    cfg->descriptor_level = 0; // level-0 description, buildStream.cpp:442-460 (Q10)
 }
 
 const char *orbfe_last_error(const orbfe_ctx *ctx) { return ctx ? ctx->err : thread_error(); }
@@ -2045,6 +2116,7 @@ int orbfe_create(const orbfe_config *cfg, orbfe_ctx **out)
     g.arc = cfg->min_arc;
     g.max_features = cfg->max_features;
     g.angle_in_radians = cfg->angle_in_radians ? 1 : 0;
+    g.descriptor_level = cfg->descriptor_level ? 1 : 0;
     size_t off = 0;
     for (int l = 0; l < g.L; l++) {
         g.lv[l].w = g.W >> l;
@@ -2098,7 +2170,8 @@ int orbfe_create(const orbfe_config *cfg, orbfe_ctx **out)
         const int n_tiles = ((g.W + 63) / 64) * ((g.H + 63) / 64);
         ctx->describe_patch = g.cap < 8 * n_tiles ? 1 : 0;
         const char *v = getenv("ORBFE_DESCRIBE"); // A/B timing of the two describe kernels on one box
-        if (v) ctx->describe_patch = !strcmp(v, "patch") ? 2 : -1;
+        if (v && !strcmp(v, "patch")) ctx->describe_patch = 2;
+        else if (v && !strcmp(v, "tile")) ctx->describe_patch = -1; // (anything else: ignored)
     }
     if (g.cap <= kMmaMaxKeypoints) { // scratch of the matrix-core matcher
         if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_mexp, B * ctx->cap_pad * 128);
@@ -2243,8 +2316,8 @@ int orbfe_detect_batch_shard(orbfe_ctx *ctx, int n_frames, int shard_index, int 
     // levels and of busy / empty image regions)
     const int n_mine = ctx->n_tiles > shard_index ? (ctx->n_tiles - shard_index + shard_count - 1) / shard_count : 0;
     if (n_mine > 0)
-        launch_detect_tiles<false>(g, dim3(n_mine, n_frames), S(stream), ctx->d_pyr, ctx->d_tiles, ctx->d_cellkey,
-                                   shard_index, shard_count, StageTiles{});
+        launch_detect_tiles(g, dim3(n_mine, n_frames), S(stream), ctx->d_pyr, ctx->d_tiles, ctx->d_cellkey, shard_index,
+                            shard_count);
     CTX_LAUNCH_CHECK(ctx, "detect_batch");
     return ORBFE_OK;
 }
@@ -2260,6 +2333,7 @@ int orbfe_export_cell_keys(orbfe_ctx *ctx, int n_frames, uint32_t *d_keys, orbfe
     if (!d_keys || n_frames < 1 || n_frames > ctx->cfg.max_batch)
         CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "export_cell_keys: bad argument");
     DeviceScope dev(ctx->cfg.device);
+    if (!dev.ok) CTX_FAIL(ctx, ORBFE_ERR_HIP, "export_cell_keys: hipSetDevice(%d) failed", ctx->cfg.device);
     ORBFE_HIP_TRY(ctx->err, hipMemcpyAsync(d_keys, ctx->d_cellkey, (size_t)n_frames * ctx->g.K * sizeof(uint32_t),
                                            hipMemcpyDeviceToDevice, S(stream)));
     return ORBFE_OK;
@@ -2271,6 +2345,7 @@ int orbfe_import_cell_keys(orbfe_ctx *ctx, int n_frames, const uint32_t *d_keys,
     if (!d_keys || n_frames < 1 || n_frames > ctx->cfg.max_batch)
         CTX_FAIL(ctx, ORBFE_ERR_INVALID_ARG, "import_cell_keys: bad argument");
     DeviceScope dev(ctx->cfg.device);
+    if (!dev.ok) CTX_FAIL(ctx, ORBFE_ERR_HIP, "import_cell_keys: hipSetDevice(%d) failed", ctx->cfg.device);
     ctx->cellkey_clean = 0;
     ORBFE_HIP_TRY(ctx->err, hipMemcpyAsync(ctx->d_cellkey, d_keys, (size_t)n_frames * ctx->g.K * sizeof(uint32_t),
                                            hipMemcpyDeviceToDevice, S(stream)));
@@ -2292,7 +2367,10 @@ int orbfe_describe_batch(orbfe_ctx *ctx, int n_frames, orbfe_keypoint *d_records
     if (soa) so = *soa;
     DeviceScope dev(ctx->cfg.device);
     if (!dev.ok) CTX_FAIL(ctx, ORBFE_ERR_HIP, "describe_batch: hipSetDevice(%d) failed", ctx->cfg.device);
-    const bool patch = ctx->describe_patch == 2 || (ctx->describe_patch == 1 && (long long)n_frames * g.cap >= 32768);
+    // (the tile kernel finds a cell's record through the 16-bit cell -> slot map, 0xFFFF = none: frames that can
+    // hold more than 65534 records take the patch kernel, which walks the 32-bit selection list)
+    const bool patch = ctx->describe_patch == 2 || (ctx->describe_patch == 1 && (long long)n_frames * g.cap >= 32768) ||
+                       g.cap > 65534;
     if (so.d_pos || so.d_score || so.d_level || so.d_angle || so.d_desc || so.d_desc32)
         hipLaunchKernelGGL(select_kernel<true>, dim3(n_frames), dim3(kSelThreads), 0, S(stream), g, ctx->d_cellkey,
                            patch ? ctx->d_sel : nullptr, ctx->d_cellslot, ctx->d_selcount, d_counts, so);
@@ -2300,21 +2378,31 @@ int orbfe_describe_batch(orbfe_ctx *ctx, int n_frames, orbfe_keypoint *d_records
         hipLaunchKernelGGL(select_kernel<false>, dim3(n_frames), dim3(kSelThreads), 0, S(stream), g, ctx->d_cellkey,
                            patch ? ctx->d_sel : nullptr, ctx->d_cellslot, ctx->d_selcount, d_counts, so);
     const bool want_soa = so.d_pos || so.d_score || so.d_level || so.d_angle || so.d_desc || so.d_desc32;
+#define ORBFE_DESCRIBE_LAUNCH2(KERNEL, DLV, GRID, ...)                                                               \
+    do {                                                                                                            \
+        if (g.angle_in_radians && want_soa) hipLaunchKernelGGL((KERNEL<19, true, DLV>), GRID, dim3(256), 0, S(stream), __VA_ARGS__);  \
+        else if (g.angle_in_radians) hipLaunchKernelGGL((KERNEL<19, false, DLV>), GRID, dim3(256), 0, S(stream), __VA_ARGS__);        \
+        else if (want_soa) hipLaunchKernelGGL((KERNEL<15, true, DLV>), GRID, dim3(256), 0, S(stream), __VA_ARGS__);                   \
+        else hipLaunchKernelGGL((KERNEL<15, false, DLV>), GRID, dim3(256), 0, S(stream), __VA_ARGS__);                                \
+    } while (0)
 #define ORBFE_DESCRIBE_LAUNCH(KERNEL, GRID, ...)                                                                    \
     do {                                                                                                            \
-        if (g.angle_in_radians && want_soa) hipLaunchKernelGGL((KERNEL<19, true>), GRID, dim3(256), 0, S(stream), __VA_ARGS__);  \
-        else if (g.angle_in_radians) hipLaunchKernelGGL((KERNEL<19, false>), GRID, dim3(256), 0, S(stream), __VA_ARGS__);        \
-        else if (want_soa) hipLaunchKernelGGL((KERNEL<15, true>), GRID, dim3(256), 0, S(stream), __VA_ARGS__);                   \
-        else hipLaunchKernelGGL((KERNEL<15, false>), GRID, dim3(256), 0, S(stream), __VA_ARGS__);                                \
+        if (g.descriptor_level) ORBFE_DESCRIBE_LAUNCH2(KERNEL, true, GRID, __VA_ARGS__);                            \
+        else ORBFE_DESCRIBE_LAUNCH2(KERNEL, false, GRID, __VA_ARGS__);                                              \
     } while (0)
     if (patch) {
         ORBFE_DESCRIBE_LAUNCH(describe_kernel, dim3((g.cap + 4 * kKpw - 1) / (4 * kKpw), n_frames), g, ctx->d_pyr, ctx->d_sel,
                               ctx->d_selcount, ctx->d_momw, d_records, so);
+    } else if (g.descriptor_level) { // one workgroup per detection tile: (level, 64x64 tile of that level)
+        if (ctx->n_tiles > 0)
+            ORBFE_DESCRIBE_LAUNCH2(describe_tile_kernel, true, dim3(ctx->n_tiles, n_frames), g, ctx->d_pyr, ctx->d_cellkey,
+                                   ctx->d_cellslot, ctx->d_momw_tile, 0, ctx->d_tiles, d_records, so);
     } else {
         const int tiles_x = (g.W + kDTile - 1) / kDTile, tiles_y = (g.H + kDTile - 1) / kDTile;
-        ORBFE_DESCRIBE_LAUNCH(describe_tile_kernel, dim3(tiles_x * tiles_y, n_frames), g, ctx->d_pyr, ctx->d_cellkey,
-                              ctx->d_cellslot, ctx->d_momw_tile, tiles_x, d_records, so);
+        ORBFE_DESCRIBE_LAUNCH2(describe_tile_kernel, false, dim3(tiles_x * tiles_y, n_frames), g, ctx->d_pyr, ctx->d_cellkey,
+                               ctx->d_cellslot, ctx->d_momw_tile, tiles_x, (const TileDesc *)nullptr, d_records, so);
     }
+#undef ORBFE_DESCRIBE_LAUNCH2
 #undef ORBFE_DESCRIBE_LAUNCH
     CTX_LAUNCH_CHECK(ctx, "describe_batch");
     return ORBFE_OK;

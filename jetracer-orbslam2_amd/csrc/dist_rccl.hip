@@ -108,7 +108,57 @@ struct orbfe_dist {
                    __FILE__, __LINE__);                                                     \
     } while (0)
 
+// Inside an ncclGroupStart() / ncclGroupEnd() pair: a failed call must still close the group before the
+// function returns, or every later call on this communicator is queued into a group that never ends.
+#define D_NCCL_G(d, expr)                                                                   \
+    do {                                                                                    \
+        ncclResult_t r_ = (expr);                                                           \
+        if (r_ != ncclSuccess) {                                                            \
+            (void)ncclGroupEnd();                                                           \
+            D_FAIL(d, ORBFE_ERR_HIP, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), \
+                   __FILE__, __LINE__);                                                     \
+        }                                                                                   \
+    } while (0)
+
+#define D_GUARD(d, g, what)                                                                 \
+    do {                                                                                    \
+        if (!(g).ok) D_FAIL(d, ORBFE_ERR_HIP, "%s: hipSetDevice(%d) failed", what, (d)->device); \
+    } while (0)
+
 static inline hipStream_t S(orbfe_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Exact-length layout on the root: record index at which frame f of rank r starts (see orbfe_dist_exact_offsets)
+__global__ void __launch_bounds__(256)
+exact_offsets_kernel(const int32_t *__restrict__ all_counts, int n_frames, int cap, int64_t *__restrict__ offsets)
+{
+    __shared__ int s_run;
+    const int r = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    for (int f0 = 0; f0 < n_frames; f0 += 256) { // chunks of 256 frames with a running base
+        const int f = f0 + tid;
+        int c = 0;
+        if (f < n_frames) {
+            c = all_counts[(size_t)r * n_frames + f];
+            c = c < 0 ? 0 : (c > cap ? cap : c);
+        }
+        // inclusive scan inside the wave, then across the four waves through LDS
+        int incl = c;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off);
+            if ((tid & 63) >= off) incl += v;
+        }
+        __shared__ int s_w[4];
+        if ((tid & 63) == 63) s_w[tid >> 6] = incl;
+        __syncthreads();
+        int before = s_run;
+        for (int w = 0; w < (tid >> 6); w++) before += s_w[w];
+        if (f < n_frames) offsets[(size_t)r * n_frames + f] = (int64_t)r * n_frames * cap + before + incl - c;
+        __syncthreads();
+        if (tid == 255) s_run = before + incl;
+        __syncthreads();
+    }
+}
 
 // cs waits for everything enqueued on the caller's stream so far
 static int order_after(orbfe_dist *d, orbfe_stream_t stream)
@@ -214,6 +264,7 @@ int orbfe_dist_wait_ticket(orbfe_dist *d, int64_t ticket, orbfe_stream_t stream)
     const int64_t oldest = d->ticket - orbfe_dist::kRing + 1;
     const int64_t t = ticket < oldest ? oldest : ticket;
     DeviceGuard g(d->device);
+    D_GUARD(d, g, "wait_ticket");
     D_HIP(d, hipStreamWaitEvent(S(stream), d->ev_done[t % orbfe_dist::kRing], 0));
     return ORBFE_OK;
 }
@@ -227,7 +278,21 @@ int orbfe_dist_sync(orbfe_dist *d)
 {
     if (!d) return ORBFE_ERR_INVALID_ARG;
     DeviceGuard g(d->device);
+    D_GUARD(d, g, "sync");
     D_HIP(d, hipStreamSynchronize(d->cs));
+    return ORBFE_OK;
+}
+
+int orbfe_dist_exact_offsets(orbfe_dist *d, const int32_t *d_all_counts, int n_frames, int cap, int64_t *d_offsets,
+                             orbfe_stream_t stream)
+{
+    if (!d) return ORBFE_ERR_INVALID_ARG;
+    if (!d_all_counts || !d_offsets || n_frames < 1 || cap < 1)
+        D_FAIL(d, ORBFE_ERR_INVALID_ARG, "exact_offsets: bad argument (n_frames %d, cap %d)", n_frames, cap);
+    DeviceGuard g(d->device);
+    D_GUARD(d, g, "exact_offsets");
+    hipLaunchKernelGGL(exact_offsets_kernel, dim3(d->world), dim3(256), 0, S(stream), d_all_counts, n_frames, cap, d_offsets);
+    D_HIP(d, hipGetLastError());
     return ORBFE_OK;
 }
 
@@ -258,9 +323,9 @@ int orbfe_dist_gather_keypoints(orbfe_dist *d, const orbfe_keypoint *d_records, 
         D_NCCL(d, ncclGroupStart());
         if (is_root) {
             for (int r = 0; r < d->world; r++)
-                if (r != root) D_NCCL(d, ncclRecv(d_all_counts + (size_t)r * n_frames, cbytes, ncclUint8, r, d->comm, d->cs));
+                if (r != root) D_NCCL_G(d, ncclRecv(d_all_counts + (size_t)r * n_frames, cbytes, ncclUint8, r, d->comm, d->cs));
         } else {
-            D_NCCL(d, ncclSend(d_counts, cbytes, ncclUint8, root, d->comm, d->cs));
+            D_NCCL_G(d, ncclSend(d_counts, cbytes, ncclUint8, root, d->comm, d->cs));
         }
         D_NCCL(d, ncclGroupEnd());
     }
@@ -273,9 +338,9 @@ int orbfe_dist_gather_keypoints(orbfe_dist *d, const orbfe_keypoint *d_records, 
             D_NCCL(d, ncclGroupStart());
             if (is_root) {
                 for (int r = 0; r < d->world; r++)
-                    if (r != root) D_NCCL(d, ncclRecv(d_all_records + (size_t)r * rstride, rbytes, ncclUint8, r, d->comm, d->cs));
+                    if (r != root) D_NCCL_G(d, ncclRecv(d_all_records + (size_t)r * rstride, rbytes, ncclUint8, r, d->comm, d->cs));
             } else {
-                D_NCCL(d, ncclSend(d_records, rbytes, ncclUint8, root, d->comm, d->cs));
+                D_NCCL_G(d, ncclSend(d_records, rbytes, ncclUint8, root, d->comm, d->cs));
             }
             D_NCCL(d, ncclGroupEnd());
         }
@@ -324,11 +389,11 @@ int orbfe_dist_gather_keypoints(orbfe_dist *d, const orbfe_keypoint *d_records, 
             for (int r = 0; r < d->world; r++) {
                 if (r == root) continue;
                 const size_t bytes = total_of(d->h_counts + (size_t)r * n_frames) * sizeof(orbfe_keypoint);
-                if (bytes) D_NCCL(d, ncclRecv(d_all_records + (size_t)r * rstride, bytes, ncclUint8, r, d->comm, d->cs));
+                if (bytes) D_NCCL_G(d, ncclRecv(d_all_records + (size_t)r * rstride, bytes, ncclUint8, r, d->comm, d->cs));
             }
         } else {
             const size_t bytes = total_of(d->h_counts) * sizeof(orbfe_keypoint);
-            if (bytes) D_NCCL(d, ncclSend(d->d_pack, bytes, ncclUint8, root, d->comm, d->cs));
+            if (bytes) D_NCCL_G(d, ncclSend(d->d_pack, bytes, ncclUint8, root, d->comm, d->cs));
         }
         D_NCCL(d, ncclGroupEnd());
     }
@@ -340,6 +405,7 @@ int orbfe_dist_allreduce_max_keys(orbfe_dist *d, uint32_t *d_keys, size_t n, orb
     if (!d) return ORBFE_ERR_INVALID_ARG;
     if (!d_keys || n == 0) D_FAIL(d, ORBFE_ERR_INVALID_ARG, "allreduce_max_keys: bad argument");
     DeviceGuard g(d->device);
+    D_GUARD(d, g, "allreduce_max_keys");
     int rc = order_after(d, stream);
     if (rc != ORBFE_OK) return rc;
     if (d->world > 1) D_NCCL(d, ncclAllReduce(d_keys, d_keys, n, ncclUint32, ncclMax, d->comm, d->cs));
@@ -352,6 +418,7 @@ int orbfe_dist_host_allreduce(orbfe_dist *d, double *values, int n, int op)
     if (!values || n < 1 || (op != 0 && op != 1)) D_FAIL(d, ORBFE_ERR_INVALID_ARG, "host_allreduce: bad argument");
     if (d->world == 1) return ORBFE_OK;
     DeviceGuard g(d->device);
+    D_GUARD(d, g, "host_allreduce");
     if (d->red_cap < n) {
         if (d->d_red) (void)hipFree(d->d_red);
         d->d_red = nullptr;

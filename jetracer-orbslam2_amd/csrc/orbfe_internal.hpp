@@ -141,6 +141,7 @@ struct DeviceGeom { // passed by value to kernels
     int threshold, arc;
     int max_features;
     int angle_in_radians;
+    int descriptor_level; // EXT iv: describe on the keypoint's own pyramid level
     size_t frame_stride;
     LevelInfo lv[kMaxLevels];
 };
@@ -153,9 +154,10 @@ void launch_match_mfma(const orbfe_keypoint *d_records, const int32_t *d_counts,
                        int32_t *d_dist, hipStream_t stream);
 
 // batch_kernels.hip: orbfe_detect of the stage API on the fused tile kernel (one launch for all levels,
-// scores also written to the caller's response maps); integer threshold, arc 9..12, dword-aligned levels
-int launch_detect_stage(const orbfe_pyramid_level *lv, int n_levels, int threshold, int arc, float *d_pos, float *d_score,
-                        int *d_level, hipStream_t stream);
+// scores also written to the caller's response maps); integer threshold, dword-aligned levels; corners are
+// decided by the caller's table d_lut, whatever it holds
+int launch_detect_stage(const orbfe_pyramid_level *lv, int n_levels, int threshold, const uint8_t *d_lut, float *d_pos,
+                        float *d_score, int *d_level, hipStream_t stream);
 
 // a per-frame count read from a caller's device buffer, made safe to index with: a stale or corrupt
 // count must not walk past the frame's cap records

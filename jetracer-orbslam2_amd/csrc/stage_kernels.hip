@@ -7,39 +7,9 @@
 #include "orbfe_internal.hpp"
 #include "device_common.hpp"
 
-#include <mutex>
-
 namespace orbfe {
 
 static thread_local char t_err[512];
-
-// Which arc length a LUT buffer was built for (orbfe_fast_calculate_lut remembers the last 16 buffers):
-// orbfe_detect takes the reference's opaque LUT pointer, but its fused path tests arcs in closed form
-// and needs the number.  An unknown pointer (a table the caller filled some other way) takes the
-// unfused path, which reads the table itself.
-static std::mutex g_lut_mutex;
-static struct { const void *ptr; int arc; } g_lut_arcs[16];
-static int g_lut_next = 0;
-
-static void remember_lut(const void *ptr, int arc)
-{
-    std::lock_guard<std::mutex> lock(g_lut_mutex);
-    for (auto &e : g_lut_arcs)
-        if (e.ptr == ptr) {
-            e.arc = arc;
-            return;
-        }
-    g_lut_arcs[g_lut_next] = {ptr, arc};
-    g_lut_next = (g_lut_next + 1) % 16;
-}
-
-static int lut_arc(const void *ptr)
-{
-    std::lock_guard<std::mutex> lock(g_lut_mutex);
-    for (auto &e : g_lut_arcs)
-        if (e.ptr == ptr) return e.arc;
-    return 0;
-}
 
 void set_thread_error(const char *fmt, ...)
 {
@@ -596,7 +566,6 @@ int orbfe_fast_calculate_lut(unsigned char *d_lut, int min_arc, orbfe_stream_t s
 {
     ARG_CHECK(d_lut && min_arc >= 1 && min_arc <= 16);
     hipLaunchKernelGGL(fast_lut_kernel, dim3(256), dim3(256), 0, S(stream), d_lut, min_arc);
-    remember_lut(d_lut, min_arc);
     return launch_status("fast_calculate_lut");
 }
 
@@ -653,9 +622,11 @@ int orbfe_detect(const orbfe_pyramid_level *lv, int n_levels, const unsigned cha
         return ORBFE_ERR_UNSUPPORTED;
     }
     // Fused path: FAST score + 3x3 NMS + cell maximum of every level in ONE launch (the batch path's tile
-    // kernel), the scores also written to the caller's response maps; needs what that kernel assumes.
-    const int arc = lut_arc(d_lut);
-    bool fused = arc >= 9 && arc <= 12 && threshold >= 1.0f && threshold <= 254.0f && threshold == (float)(int)threshold;
+    // kernel, instantiated table-driven: the reference's own prechecks, then lut[dark] | lut[bright] per
+    // candidate, so d_lut stays the opaque table of fast.cuh:42-48 -- nothing is remembered about how or
+    // where it was built), the scores also written to the caller's response maps; needs an integer threshold
+    // (the kernel's packed-u16 arithmetic) and dword-aligned levels.
+    bool fused = threshold >= 1.0f && threshold <= 254.0f && threshold == (float)(int)threshold;
     for (int i = 0; i < n_levels && fused; i++) {
         ARG_CHECK(lv[i].image && lv[i].image_pitch >= lv[i].image_width);
         ARG_CHECK(!lv[i].response || lv[i].response_pitch >= lv[i].image_width * sizeof(float));
@@ -663,7 +634,7 @@ int orbfe_detect(const orbfe_pyramid_level *lv, int n_levels, const unsigned cha
                 lv[i].image_pitch < (1u << 24) && lv[i].image_width > 0 && lv[i].image_height > 0;
     }
     if (fused) {
-        const int rc = launch_detect_stage(lv, n_levels, (int)threshold, arc, d_pos, d_score, d_level, S(stream));
+        const int rc = launch_detect_stage(lv, n_levels, (int)threshold, d_lut, d_pos, d_score, d_level, S(stream));
         if (rc != ORBFE_OK) set_thread_error("detect: launch failed");
         return rc;
     }

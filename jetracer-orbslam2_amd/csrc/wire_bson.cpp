@@ -130,7 +130,7 @@ static void frame_items(const orbfe_frame_message *m, int32_t scalars[6], Item i
     scalars[3] = m->width;
     scalars[4] = m->height;
     scalars[5] = m->channels;
-    static const char *names[9] = {"ax", "ay", "az", "width", "height", "channels", "keypoints_x", "keypoints_y", "image"};
+    static const char names[9][12] = {"ax", "ay", "az", "width", "height", "channels", "keypoints_x", "keypoints_y", "image"};
     for (int i = 0; i < 6; i++) items[i] = Item{names[i], ORBFE_BSON_INT32, &scalars[i], 4u};
     const uint32_t kb = (uint32_t)(m->matched_keypoints > 0 ? m->matched_keypoints : 0) * (uint32_t)sizeof(uint16_t);
     items[6] = Item{names[6], ORBFE_BSON_BINARY, m->keypoints_x, kb};

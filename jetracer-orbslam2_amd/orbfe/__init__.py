@@ -41,7 +41,7 @@ class Config(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("levels", C.c_int32),
                 ("cell", C.c_int32), ("fast_threshold", C.c_int32), ("min_arc", C.c_int32),
                 ("max_features", C.c_int32), ("angle_in_radians", C.c_int32),
-                ("max_batch", C.c_int32), ("device", C.c_int32)]
+                ("max_batch", C.c_int32), ("device", C.c_int32), ("descriptor_level", C.c_int32)]
 
 
 class Intrinsics(C.Structure):  # orbfe_intrinsics == rs2_intrinsics
@@ -199,10 +199,10 @@ class Context:
     """RAII wrapper of orbfe_ctx (batch API)."""
 
     def __init__(self, width, height, levels=1, cell=32, fast_threshold=13, min_arc=12,
-                 max_features=0, angle_in_radians=0, max_batch=1, device=0):
+                 max_features=0, angle_in_radians=0, max_batch=1, device=0, descriptor_level=0):
         L = lib()
         self.cfg = Config(width, height, levels, cell, fast_threshold, min_arc, max_features,
-                          angle_in_radians, max_batch, device)
+                          angle_in_radians, max_batch, device, descriptor_level)
         h = C.c_void_p()
         check(L.orbfe_create(C.byref(self.cfg), C.byref(h)))
         self.handle = h

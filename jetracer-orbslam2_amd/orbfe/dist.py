@@ -31,6 +31,7 @@ _DIST_SIGS = {
     "orbfe_dist_shard_range": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "orbfe_dist_gather_keypoints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                               C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "orbfe_dist_exact_offsets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "orbfe_dist_allreduce_max_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "orbfe_dist_wait": (C.c_int, [C.c_void_p, C.c_void_p]),
     "orbfe_dist_ticket": (C.c_int64, [C.c_void_p]),
@@ -88,6 +89,10 @@ class RcclComm:
         """Pointers are device addresses (ints); all_* may be None off the root."""
         self._check(dist_lib().orbfe_dist_gather_keypoints(self.handle, records, counts, n_frames, cap, all_records,
                                                            all_counts, root, int(bool(exact)), stream), self.handle)
+
+    def exact_offsets(self, all_counts, n_frames, cap, offsets, stream):
+        """Root: record index where each (rank, frame) starts in the exact-length layout -> int64[world * n_frames]."""
+        self._check(dist_lib().orbfe_dist_exact_offsets(self.handle, all_counts, n_frames, cap, offsets, stream), self.handle)
 
     def allreduce_max_keys(self, keys, n, stream):
         self._check(dist_lib().orbfe_dist_allreduce_max_keys(self.handle, keys, n, stream), self.handle)

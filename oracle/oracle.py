@@ -32,7 +32,7 @@ class Level(C.Structure):
 class Config(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("levels", C.c_int), ("cell", C.c_int),
                 ("fast_threshold", C.c_float), ("min_arc", C.c_int), ("max_features", C.c_int),
-                ("angle_in_radians", C.c_int)]
+                ("angle_in_radians", C.c_int), ("descriptor_level", C.c_int)]
 
 
 KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("score", "<f4"), ("level", "<i4"),
@@ -60,9 +60,9 @@ def _p(a):
 
 
 def make_config(width, height, levels=1, cell=32, fast_threshold=13.0, min_arc=12,
-                max_features=0, angle_in_radians=0):
+                max_features=0, angle_in_radians=0, descriptor_level=0):
     return Config(width, height, levels, cell, fast_threshold, min_arc, max_features,
-                  angle_in_radians)
+                  angle_in_radians, descriptor_level)
 
 
 def level_dims(width, height, level):

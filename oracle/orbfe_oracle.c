@@ -827,15 +827,18 @@ int oracle_extract_frame(const oracle_config *cfg, const uint8_t *gray, int gray
         for (int i = cfg->max_features; i < n; i++) sel_score[s[i].cell] = 0.0f;
         free(s);
     }
-    /* orientation + descriptor on the level-0 image only (Q10), selected cells only */
-    oracle_compute_fast_angle(angle, pos, sel_score, lv[0].image, lv[0].image_pitch, cfg->width,
-                              cfg->height, K);
+    /* orientation + descriptor, selected cells only: on the level-0 image at the level-0 position (Q10,
+     * buildStream.cpp:442-460), or -- EXT iv, descriptor_level -- on the level that won the cell at
+     * pos / 2^level (exact: pos = level coordinate << level, nms.cu:246-252), with that level's width and
+     * height in every bound and guard band of orb.cu:77-142 and :17-75 */
     for (int k = 0; k < K; k++) {
-        if (sel_score[k] > 0.0f)
-            oracle_calc_orb(angle + k, pos + 2 * k, desc + 32 * (size_t)k, desc32 + k,
-                            lv[0].image, lv[0].image_pitch, cfg->width, cfg->height, 1,
-                            cfg->angle_in_radians);
-        /* else: zero descriptor, zero desc32, zero angle (Q5) -- calloc */
+        if (!(sel_score[k] > 0.0f)) continue; /* zero descriptor, zero desc32, zero angle (Q5) -- calloc */
+        const int l = cfg->descriptor_level ? level[k] : 0;
+        const float pl[2] = {pos[2 * k] / (float)(1 << l), pos[2 * k + 1] / (float)(1 << l)};
+        oracle_compute_fast_angle(angle + k, pl, NULL, lv[l].image, lv[l].image_pitch, lv[l].width,
+                                  lv[l].height, 1);
+        oracle_calc_orb(angle + k, pl, desc + 32 * (size_t)k, desc32 + k, lv[l].image,
+                        lv[l].image_pitch, lv[l].width, lv[l].height, 1, cfg->angle_in_radians);
     }
     int count = 0;
     for (int k = 0; k < K; k++)

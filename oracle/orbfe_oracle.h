@@ -37,6 +37,9 @@ typedef struct oracle_config {
     int min_arc;          /* reference 12 */
     int max_features;     /* 0 = every non-empty cell (reference); >0 = top-N */
     int angle_in_radians; /* 0 = reference quirk Q7 */
+    int descriptor_level; /* 0 = reference quirk Q10 (orientation + descriptor always on level 0,
+                             buildStream.cpp:442-460); 1 = EXT iv: on the pyramid level that won the cell,
+                             at pos / 2^level, image bounds and guard bands in that level's coordinates */
 } oracle_config;
 
 /* 52-byte keypoint record */

@@ -30,13 +30,14 @@ def test_library_exports_every_declared_symbol():
     lib = orbfe.lib()  # raises if liborbfe.so has not been built
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.orbfe_version() == 1
+    assert lib.orbfe_version() == 2
     assert lib.orbfe_load_pattern() == orbfe.OK
 
 
 def test_struct_layouts_match_the_header():
     import orbfe
-    assert C.sizeof(orbfe.Config) == 40
+    assert C.sizeof(orbfe.Config) == 44  # 11 int32: ... max_batch, device, descriptor_level (ORBFE_VERSION 2)
+    assert orbfe.Config.descriptor_level.offset == 40
     assert C.sizeof(orbfe.PyramidLevel) == 48  # size_t x3, ptr, size_t, ptr
     assert C.sizeof(orbfe.Soa) == 48
     assert orbfe.KEYPOINT_DTYPE.itemsize == 52
@@ -75,3 +76,28 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(orbfe, "LIB_PATH", "/nonexistent/liborbfe.so")
     with pytest.raises(orbfe.OrbfeError):
         orbfe.lib()
+
+
+def test_library_keeps_no_mutable_global_state():
+    """include/orbfe.h promises "no global mutable state" (a process-global LUT-pointer -> arc table sat
+    behind orbfe_detect).  Every writable data symbol of liborbfe.so must be toolchain / HIP-runtime plumbing
+    (kernel handles and the fat-binary handle, written once at load) or the thread-local error text."""
+    import subprocess
+    import orbfe
+    if not os.path.exists(orbfe.LIB_PATH):
+        pytest.skip("library not built")
+    out = subprocess.run(["nm", "-C", orbfe.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    bad = []
+    for line in out.splitlines():
+        parts = line.split(None, 2)
+        if len(parts) < 3 or parts[1] not in "bBdD":
+            continue
+        name = parts[2]
+        plumbing = (name.startswith(("__hip", "_DYNAMIC", "_GLOBAL_OFFSET_TABLE_", "DW.ref", "__dso_handle", "completed.",
+                                     "__TMC_END__", "__bss_start", "_edata", "_end", "__data_start", "__frame_dummy",
+                                     "__do_global", "guard variable", "__do_init", "__do_fini", "__init", "__fini"))  # HIP module ctor / dtor
+                    or "_kernel" in name           # device-stub handles hipcc emits per __global__ function
+                    or "t_err" in name)            # thread_local text behind orbfe_last_error(NULL)
+        if not plumbing:
+            bad.append(line)
+    assert not bad, "writable static storage in liborbfe.so:\n" + "\n".join(bad)

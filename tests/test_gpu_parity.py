@@ -319,7 +319,8 @@ def _check_extract(oracle_mod, ctx, frames, records, counts, soa_np, **cfg):
                                   fast_threshold=float(cfg.get("fast_threshold", 13)),
                                   min_arc=cfg.get("min_arc", 12),
                                   max_features=cfg.get("max_features", 0),
-                                  angle_in_radians=cfg.get("angle_in_radians", 0))
+                                  angle_in_radians=cfg.get("angle_in_radians", 0),
+                                  descriptor_level=cfg.get("descriptor_level", 0))
     total = 0
     for f in range(n):
         ref = oracle_mod.extract_frame(frames[f], ocfg, want_pyramid=True)

@@ -325,9 +325,12 @@ def test_cpp_match_port(gpu, oracle_mod, tmp_path):
 
 
 # ------------------------------------------------------------------ stage API detect: fused path, float thresholds
-def _detect_case(torch, orbfe, oracle_mod, w, h, levels, arc, thr, build_lut_on_device, pitch_extra, with_resp=True, seed=9):
+def _detect_case(torch, orbfe, oracle_mod, w, h, levels, arc, thr, build_lut_on_device, pitch_extra, with_resp=True, seed=9,
+                 lut_np=None, make_d_lut=None):
+    """lut_np: the table the oracle uses (default: the arc table); make_d_lut(lut_np) -> device tensor holding it,
+    however it got there (default: orbfe_fast_calculate_lut on the device, or a plain upload)."""
     from test_gpu_parity import bits, pitched
-    lut = oracle_mod.fast_lut(arc)
+    lut = oracle_mod.fast_lut(arc) if lut_np is None else lut_np
     imgs = [oracle_mod.gaussian_blur_3x3(synth.frame(w, h, seed, "rects", **synth.DENSE))]
     for _ in range(1, levels):
         imgs.append(oracle_mod.halfsample(imgs[-1]))
@@ -339,7 +342,9 @@ def _detect_case(torch, orbfe, oracle_mod, w, h, levels, arc, thr, build_lut_on_
     d_res = [torch.full((max(h >> l, 1), (w >> l) + 5), -1.0, dtype=torch.float32, device="cuda") for l in range(levels)]
     lv = orbfe.make_levels([(d_img[l].data_ptr(), w >> l, h >> l, pitch[l]) for l in range(levels)],
                            [(d_res[l].data_ptr() if with_resp else 0, w >> l, h >> l, ((w >> l) + 5) * 4) for l in range(levels)])
-    if build_lut_on_device:
+    if make_d_lut is not None:
+        d_lut = make_d_lut(lut)
+    elif build_lut_on_device:
         d_lut = torch.zeros(65536, dtype=torch.uint8, device="cuda")
         orbfe.check(orbfe.lib().orbfe_fast_calculate_lut(d_lut.data_ptr(), arc, stream(torch)))
     else:
