@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- ORB front-end throughput on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode c2|ref|c3|c4|c5] [--scene dense|survey]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode c2|ref|c3|c4|c5|match] [--scene dense|survey]
 
 One "step" = one pass of the hot path over one batch of synthetic frames already resident in HBM:
 orbfe_extract (blur + pyramid -> fused FAST/NMS -> selection -> orientation + rBRIEF -> 52-byte
@@ -10,7 +10,9 @@ records) followed by the Hamming matcher.  Rank 0 prints ONE JSON line.
 Modes (BASELINE.json configs):
   c2   configs[1], the metric: 640x480 mono, 8-level pyramid, 2000 features/frame; here cell 8
        (4800 cells, detection on levels 0..3), FAST-9 t = 13, top-2000 by (score desc, cell asc),
-       256-bit brute-force matching t-1 -> t; 256 frames per GPU per step (weak scaling).
+       256-bit brute-force matching t-1 -> t; 2048 frames per GPU per step (weak scaling; 2.5 GB of
+       inputs, pyramids, records and matcher scratch resident in HBM, far beyond the 256 MB Infinity
+       Cache, so no step finds its data cached by the previous one; --batch 256 is round 1-2's size).
   ref  the reference-parity configuration (cell 32, FAST-12, 6 levels, <= 300 keypoints, 32-bit
        windowed matcher) -- a parity case, not the metric.
   c3   configs[2]: RealSense-shaped stereo 848x480 pairs (right = left shifted 3 px + noise),
@@ -19,6 +21,9 @@ Modes (BASELINE.json configs):
        gathered on rank 0.
   c5   configs[4]: ONE 3840x2160 frame, 12 levels, 8000 features; detection tiles sharded over the
        ranks, per-cell keys merged by all-reduce(MAX), then selection + description.
+  match  SURVEY.md 8d's matcher microbench: nA = nB in {405, 2000, 8192}, random 256-bit descriptors
+       (C3's reference shape, C2/C3's budget, C5's), brute force 256-bit and the reference's 32-bit /
+       +-2 px window form; one JSON line with Gpairs/s and the MFMA fraction per size.  1 GPU.
 
 Multi-GPU: one process per GPU.  Under torchrun (WORLD_SIZE set) this process is one rank; with
 --gpus N > 1 and no WORLD_SIZE the parent starts N child ranks itself BEFORE touching the GPU and
@@ -42,7 +47,7 @@ sys.path.insert(0, os.path.join(ROOT, "jetracer-orbslam2_amd"))
 
 EXT = dict(levels=8, cell=8, min_arc=9, max_features=2000)
 MODES = {
-    "c2": dict(width=640, height=480, cfg=EXT, match=dict(mode=1, window=-1, max_distance=256), batch=256, stride=1,
+    "c2": dict(width=640, height=480, cfg=EXT, match=dict(mode=1, window=-1, max_distance=256), batch=2048, stride=1,
                scaling="weak",
                workload="640x480 mono, 8-level pyramid, 2000 features/frame (cell 8, FAST-9 t=13, top-2000), "
                         "256-bit brute-force match t-1->t"),
@@ -129,6 +134,20 @@ def cpu_model():
     return "unknown"
 
 
+def cpu_share():
+    """(threads to use, affinity count, cgroup CPU quota or None) of this process: the affinity mask, cut to the
+    cgroup's cpu.max quota when there is one (a 1-GPU box is a 16-CPU share of a larger host)."""
+    n = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(float(q) / float(per) + 0.5))
+    except (OSError, ValueError):
+        pass
+    return (min(n, quota) if quota else n), n, quota
+
+
 def cpu_baseline(frames, mode, seconds_1t=7.0, seconds_mt=10.0):
     """Oracle (CPU port of the reference semantics) timed on this host: extract + match, first on
     one thread, then frame-parallel on the box's CPU share."""
@@ -138,7 +157,7 @@ def cpu_baseline(frames, mode, seconds_1t=7.0, seconds_mt=10.0):
     from concurrent.futures import ThreadPoolExecutor
     m = MODES[mode]
     ocfg = oracle.make_config(m["width"], m["height"], **m["cfg"])
-    cores = max(1, min(len(os.sched_getaffinity(0)), 16))  # a 1-GPU box has a 16-CPU share
+    cores, affinity, quota = cpu_share()  # the threads actually used = what is reported as `cores`
     mm = m["match"]
 
     def comp(d):
@@ -182,7 +201,7 @@ def cpu_baseline(frames, mode, seconds_1t=7.0, seconds_mt=10.0):
 
     v1, f1, n1, p1, t1 = run(1, seconds_1t)
     vm, fm, nm, pm, tm = run(cores, seconds_mt)
-    return dict(value=vm, unit="keypoints/s", cores=cores, kind="port", frames_per_s=fm,
+    return dict(value=vm, unit="keypoints/s", cores=cores, affinity_cpus=affinity, cgroup_cpu_quota=quota, kind="port", frames_per_s=fm,
                 single_thread=dict(value=v1, unit="keypoints/s", cores=1, frames_per_s=f1,
                                    sample="%d frames + %d pairs in %.1f s" % (n1, p1, t1)),
                 cpu_model=cpu_model(),
@@ -208,18 +227,123 @@ def make_scenes(synth, mode, scene, n_distinct, first_index):
     return synth.frames(w, h, n_distinct, first_index=first_index, kind="rects", **kw)
 
 
+MATCH_SIZES = [  # nA = nB in {405, 2000, 8192}; a context whose record capacity is exactly n
+    dict(n=405, width=848, height=480, cfg=dict(levels=1, cell=32, min_arc=12, max_features=0), frames=256,
+         shape="C3 reference regime: 848x480, one keypoint per 32-px cell"),
+    dict(n=2000, width=848, height=480, cfg=dict(levels=1, cell=8, min_arc=9, max_features=2000), frames=256,
+         shape="C2 / C3 feature budget"),
+    dict(n=8192, width=3840, height=2160, cfg=dict(levels=1, cell=16, min_arc=9, max_features=8192), frames=16,
+         shape="C5: one 3840x2160 frame's budget"),
+]
+
+
+def match_microbench(args, torch, np, orbfe, dev, json_out):
+    """--mode match: the matcher alone on random 256-bit descriptors (post_processing.cu:92-200 is the reference
+    matcher).  Records are synthetic: keypoint i of every frame sits at the centre of cell i (cell order, as
+    extraction emits them), odd frames shifted by one pixel, descriptors i.i.d. random; all n records valid."""
+    s = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(20261004)
+    out_sizes = []
+    for S in MATCH_SIZES:
+        n, w, h, B = S["n"], S["width"], S["height"], S["frames"]
+        ctx = orbfe.Context(w, h, max_batch=B, **S["cfg"])
+        assert ctx.cap == n, (ctx.cap, n)
+        cell = S["cfg"]["cell"]
+        cells_x = (w + cell - 1) // cell
+        k = np.sort(rng.choice(ctx.K, n, replace=False)) if n < ctx.K else np.arange(n)
+        rec = np.zeros((B, n), dtype=orbfe.KEYPOINT_DTYPE)
+        rec["x"] = np.minimum((k % cells_x) * cell + cell // 2, w - 1)[None, :] + (np.arange(B) % 2)[:, None]
+        rec["y"] = np.minimum((k // cells_x) * cell + cell // 2, h - 1)[None, :]
+        rec["score"], rec["level"] = 100.0, 0
+        rec["desc"] = rng.integers(0, 256, (B, n, 32), dtype=np.uint8)
+        d_rec = torch.from_numpy(rec.view(np.uint8).reshape(-1)).to(dev)
+        d_cnt = torch.full((B,), n, dtype=torch.int32, device=dev)
+        d_idx = torch.zeros((B - 1) * n, dtype=torch.int32, device=dev)
+        d_dst = torch.zeros((B - 1) * n, dtype=torch.int32, device=dev)
+        pairs = (B - 1) * n * n
+        entry = {"n": n, "frames_per_call": B, "frame_pairs_per_call": B - 1, "descriptor_pairs_per_call": pairs,
+                 "shape": S["shape"], "algorithmic_bytes_per_call": {}}
+        for label, mode, window, maxd, per in (("brute_force_256bit", 1, -1, 256, 40), ("reference_32bit_window2", 0, 2, 4, 12)):
+            def call():
+                ctx.match_batch(d_rec.data_ptr(), d_cnt.data_ptr(), B, mode, window, maxd, d_idx.data_ptr(), d_dst.data_ptr(), s)
+            for _ in range(10):
+                call()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            call()
+            e1.record()
+            torch.cuda.synchronize()
+            reps = max(10, min(2000, int(100.0 / max(e0.elapsed_time(e1), 1e-3))))  # ~100 ms of calls
+            e0.record()
+            for _ in range(reps):
+                call()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            disp = ctx.dispatch_info(B, mode, window)
+            ab = (per * 2 * n + 8 * n) * (B - 1)  # SURVEY.md 8d: B_match = per * (nA + nB) + 8 * nA per frame pair
+            r = {"ms_per_call": ms, "calls_timed": reps, "kernels": disp["match"], "examines": disp["match_examines"],
+                 "algorithmic_bytes_per_call": ab, "hbm_frac_of_8TBps": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                 "matched": int((d_idx[:n] >= 0).sum().item())}
+            if disp["match_examines"] == "all_pairs":
+                r["gpairs_per_s"] = pairs / (ms * 1e-3) / 1e9
+                if "mfma" in disp["match"]:
+                    r["mfma"] = {"bound": "mfma", "unit": "TFLOP/s", "peak": FP4_MFMA_PEAK_TFLOPS,
+                                 "achieved": 512.0 * pairs / (ms * 1e-3) / 1e12,
+                                 "frac": 512.0 * pairs / (ms * 1e-3) / 1e12 / FP4_MFMA_PEAK_TFLOPS}
+            else:  # the cell index looks only at the candidates inside the window: nA * nB is what the REFERENCE would visit
+                r["nominal_gpairs_per_s"] = pairs / (ms * 1e-3) / 1e9
+                r["note"] = ("the reference visits all nA x nB pairs (post_processing.cu:134-170); the cell-indexed kernel "
+                             "examines only the window's cells, so this is an equivalent rate, not comparisons done")
+            entry[label] = r
+        out_sizes.append(entry)
+        ctx.close()
+        del d_rec, d_idx, d_dst
+    head = next(e for e in out_sizes if e["n"] == 2000)["brute_force_256bit"]
+    out = {"metric": "matcher Gpairs/sec, brute-force 256-bit Hamming, nA = nB = 2000 (SURVEY.md 8d microbench)",
+           "value": head["gpairs_per_s"], "unit": "Gpairs/s", "n_gpus": 1, "steps": head["calls_timed"], "warmup": 10,
+           "ms_per_step": head["ms_per_call"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "u8 (exact Hamming distance as an e2m1 matrix product, f32 accumulate)", "data": "synthetic",
+           "config": {"workload": "matcher microbench: nA = nB in {405, 2000, 8192}, random 256-bit descriptors, "
+                                  "brute force 256-bit and reference 32-bit / +-2 px window", "mode": "match"},
+           "roofline": dict(head["mfma"], kernel=head["kernels"], note="the matcher's roof is the matrix cores (dense FP4 "
+                            "MFMA peak ~10 PFLOP/s), its HBM traffic is negligible by construction (SURVEY.md 8d)",
+                            hbm={"bound": "hbm", "frac": head["hbm_frac_of_8TBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                 "achieved": head["hbm_frac_of_8TBps"] * HBM_PEAK_GBPS, "traffic": None}),
+           "sizes": out_sizes, "cpu_baseline": None}
+    if not args.no_cpu_baseline:  # the oracle's brute-force matcher on one thread, a bounded sample
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle
+        a = rng.integers(0, 256, (2000, 32), dtype=np.uint8)
+        b = rng.integers(0, 256, (2000, 32), dtype=np.uint8)
+        t0, calls = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 5.0:
+            oracle.match256(a, b)
+            calls += 1
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": calls * 4e6 / dt / 1e9, "unit": "Gpairs/s", "cores": 1, "kind": "port",
+                               "cpu_model": cpu_model(), "sample": "%d calls of oracle_match256 (2000 x 2000) in %.1f s" % (calls, dt)}
+    json_out.write(json.dumps(out) + "\n")
+    json_out.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", choices=sorted(MODES), default="c2")
+    ap.add_argument("--mode", choices=sorted(MODES) + ["match"], default="c2")
     ap.add_argument("--batch", type=int, default=0, help="frames per GPU per step (c2/ref/c3), total frames (c4); "
                                                            "0 = the mode's default")
     ap.add_argument("--scene", choices=("dense", "survey"), default="dense")
     ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic frames per rank (repeated to fill the batch)")
-    ap.add_argument("--prewarm", type=int, default=100,
-                    help="untimed steps issued before the warm-up steps so that the clocks have settled (not counted)")
+    ap.add_argument("--prewarm", type=int, default=-1,
+                    help="untimed steps issued before the warm-up steps so that the clocks have settled (not counted); "
+                         "-1 = about 50 ms worth of them")
+    ap.add_argument("--rotate", type=int, default=1,
+                    help="cycle this many distinct resident input batches (step i reads batch i %% k): shows the rate "
+                         "does not depend on a step finding the previous step's data in cache")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (survey scene, no-gather rate)")
     ap.add_argument("--rgb", action="store_true",
@@ -304,6 +428,11 @@ def main():
             comm.close()
             comm = None
 
+    if args.mode == "match":
+        if world != 1:
+            sys.exit("bench.py: --mode match is a single-GPU microbench")
+        match_microbench(args, torch, np, orbfe, dev, json_out)
+        return
     m = MODES[args.mode]
     w, h = m["width"], m["height"]
     total = args.batch or m["batch"]
@@ -317,12 +446,12 @@ def main():
     mm = m["match"]
     s = torch.cuda.current_stream().cuda_stream
 
-    def build_input(scene):
+    def build_input(scene, variant=0):
         n_distinct = max(min(args.distinct, B), 1)
         if args.mode == "c3":
             n_distinct += n_distinct % 2
         # every rank sees different scenes; strong-scaling modes index them by global frame number
-        first = (f0 if m["scaling"] == "strong" else 1000 * rank)
+        first = (f0 if m["scaling"] == "strong" else 1000 * rank) + 100000 * variant
         base = make_scenes(synth, args.mode, scene, n_distinct, first)
         fr = torch.from_numpy(base).to(dev)[torch.arange(B, device=dev) % len(base)].contiguous()
         if args.rgb:  # R = G = B = gray scene +- a channel-dependent offset: corners survive the conversion
@@ -348,12 +477,12 @@ def main():
         if not args.exact_gather:  # rank 0 extracts straight into its own block of the gathered arrays: no local copy
             recs = [gather_out[b][0][0] for b in range(2)]
             cnts = [gather_out[b][1][0] for b in range(2)]
-    state = dict(frames=None, step=0, tickets=[0, 0], pending=[None, None], events=[])
+    state = dict(frames=None, step=0, tickets=[0, 0], pending=[None, None], events=[], prewarm=0)
 
     def run_step(record, do_gather):
         b = state["step"] & 1
+        frames = state["frames"][state["step"] % len(state["frames"])]  # --rotate: another resident batch every step
         state["step"] += 1
-        frames = state["frames"]
         if do_gather:  # the gather that last read this buffer pair must be done before it is rewritten
             if comm is not None:
                 comm.wait_ticket(state["tickets"][b], s)
@@ -417,11 +546,11 @@ def main():
 
     def timed(frames, do_gather, record, steps=None):
         steps = steps or args.steps
-        state["frames"] = frames
+        state["frames"] = frames if isinstance(frames, list) else [frames]
         state["events"] = []
         # the clocks take ~50 ms of load to settle (measured: 0.522 ms per step after 3 warm-up steps, 0.497
         # after 20, 0.484 after 100, 0.482 over 200 timed steps): settle first, then the W warm-up steps
-        for _ in range(args.prewarm):
+        for _ in range(state["prewarm"]):
             run_step(False, do_gather)
         sync()
         for _ in range(args.warmup):
@@ -454,6 +583,11 @@ def main():
 
     use_gather = gather_ok and not args.no_gather
     base, frames = build_input(args.scene)
+    if args.rotate > 1:
+        frames = [frames] + [build_input(args.scene, v)[1] for v in range(1, args.rotate)]
+    # clock settling: ~50 ms of load before the warm-up steps (0.522 ms per 256-frame step after 3 warm-up steps,
+    # 0.484 after 100); a step's length is not known yet, so estimate it from the frame count
+    state["prewarm"] = args.prewarm if args.prewarm >= 0 else max(4, min(100, int(100 * 256 * 307200 / max(B * w * h, 1))))
     main_run = timed(frames, use_gather, True)
     extras = {}
     if not args.no_extras:
@@ -497,19 +631,28 @@ def main():
             ab["match"] = float((per * (a_ + b_) + 8 * a_).sum()) / B  # descriptor + position in, (idx, dist) out
         else:
             ab["match"] = 0.0
-        mfma_match = bool(mm) and mm["mode"] == 1 and mm["window"] < 0
-        kernels = {"pyramid": "pyramid_fused_kernel", "detect": "detect_tile_kernel",
-                   "describe": "select_kernel+describe_kernel",
-                   "match": ("match_expand_kernel+match_mfma_kernel" if mfma_match else
-                             "match_gather_kernel+match_batch_256_kernel" if (mm and mm["mode"] == 1) else
-                             "match_batch_ref_kernel")}
-        prof = {}
+        # the kernels this context actually runs for this call size (the library picks the describe and match kernels)
+        disp = ctx.dispatch_info(max(B, 1), mm["mode"] if mm else 1, mm["window"] if mm else -1)
+        if not mm:
+            disp["match"], disp["match_examines"] = None, None
+        mfma_match = bool(mm) and "match_mfma_kernel" in (disp["match"] or "")
+        kernels = {k: disp[k] for k in names}
+        # PMC-derived numbers (profiles/traffic.json: rocprofv3 --pmc passes, tools/collect_profiles.sh) are used only
+        # when they were measured on THIS source (orbfe.source_hash()); they are per launch of `batch` frames and scale
+        # linearly with the frames of a launch
+        prof, pmc = {}, {"source": "profiles/traffic.json", "csrc_sha256_built": orbfe.source_hash()}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and B == 256:  # the PMC passes were taken at batch 256
-            try:
-                prof = json.load(open(tpath)).get(args.mode, {})
-            except Exception:
-                prof = {}
+        try:
+            prof = json.load(open(tpath)).get(args.mode, {})
+        except Exception:
+            prof = {}
+        pmc["csrc_sha256_measured"] = prof.get("csrc_sha256")
+        pmc["stale"] = not prof or prof.get("csrc_sha256") != pmc["csrc_sha256_built"]
+        if pmc["stale"]:
+            pmc["note"] = ("no PMC passes for these sources: traffic / VALU fields are null (re-run tools/collect_profiles.sh "
+                           "and commit profiles/traffic.json)")
+            prof = {}
+        scale = B / float(prof.get("batch", 256)) if prof else 0.0
         valu_counts = prof.get("valu_wave_instructions", {})
         per_stage = {}
         for k in names:
@@ -518,11 +661,12 @@ def main():
                 continue
             e = {"kernel": kernels[k], "ms": stages[k], "algorithmic_bytes": ab[k] * B,
                  "achieved_GBps": ab[k] * B / t / 1e9, "frac": ab[k] * B / t / 1e9 / HBM_PEAK_GBPS,
-                 "traffic": prof.get(k)}
+                 "traffic": prof[k] * scale if prof.get(k) else None}
             if valu_counts.get(k):  # VALU wave-instructions per launch (rocprofv3 SQ_INSTS_VALU) x 64 lanes
-                ach = valu_counts[k] * 64 / t / 1e12
+                ach = valu_counts[k] * scale * 64 / t / 1e12
                 e["valu"] = {"bound": "valu", "unit": "Tlane-op/s", "achieved": ach, "peak": VALU_PEAK_TLANEOPS,
-                             "frac": ach / VALU_PEAK_TLANEOPS, "wave_instructions_per_launch": valu_counts[k]}
+                             "frac": ach / VALU_PEAK_TLANEOPS, "wave_instructions_per_launch": valu_counts[k] * scale,
+                             "lane_ops_per_level0_pixel": valu_counts[k] * scale * 64 / (B * w * h)}
                 # share of SIMD cycles with a VALU instruction executing (SQ_ACTIVE_INST_VALU, same PMC pass): the
                 # lane-op fraction prices every instruction at full rate, the mix here is largely half-rate
                 busy = prof.get("valu_pipe_busy", {}).get(k)
@@ -538,31 +682,28 @@ def main():
                                           "achieved": flops / t / 1e12, "frac": flops / t / 1e12 / FP4_MFMA_PEAK_TFLOPS,
                                           "flops_per_launch": flops}
         dom = max(per_stage, key=lambda k: stages[k])  # the kernel with the largest share of the step
-        ms_extract = stages["pyramid"] + stages["detect"] + stages["describe"]
-        hbm = {"bound": "hbm", "achieved": per_stage[dom]["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-               "frac": per_stage[dom]["frac"], "traffic": per_stage[dom]["traffic"]}
-        # what bounds the dominant kernel: the PMC passes (profiles/) show detect and describe at 75-90 %
-        # VALU busy and a few % of the HBM roofline, the pyramid kernel at 63 % of it
+        # The tier's declared roofline is HBM: `roofline.frac` = algorithmic bytes of the dominant kernel / its launch
+        # time / 8 TB/s.  What the counters show limits that kernel (vector-instruction issue for detect and describe,
+        # the matrix cores for the brute-force matcher) sits beside it as named sub-objects, never in `frac`.
         limiter = "valu" if dom in ("detect", "describe") else ("mfma" if dom == "match" and mfma_match else "hbm")
-        roof = dict(hbm)
-        if limiter == "valu" and "valu" in per_stage[dom]:
-            roof = dict(per_stage[dom]["valu"])
-            roof["traffic"] = per_stage[dom]["traffic"]
-        elif limiter == "mfma":
-            roof = dict(per_stage[dom]["mfma"])
-            roof["traffic"] = per_stage[dom]["traffic"]
-        roof.update({"kernel": kernels[dom], "limiter": limiter, "hbm": hbm,
-                     "algorithmic_bytes_per_launch": ab[dom] * B, "avg_launch_ms": stages[dom],
-                     "note": "declared roofline of the tier is HBM (`hbm`: algorithmic bytes / launch time / 8 TB/s); "
-                             "`bound` is what the counters show limits the dominant kernel (DESIGN.md section 4)",
-                     "stages": per_stage})
+        roof = {"bound": "hbm", "achieved": per_stage[dom]["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": per_stage[dom]["frac"], "traffic": per_stage[dom]["traffic"],
+                "kernel": kernels[dom], "stage": dom, "algorithmic_bytes_per_launch": ab[dom] * B,
+                "avg_launch_ms": stages[dom], "frames_per_launch": B,
+                "limiter": limiter, "valu": per_stage[dom].get("valu"), "mfma": per_stage[dom].get("mfma"),
+                "pmc": pmc,
+                "note": "frac = algorithmic bytes / launch time / 8 TB/s for the kernel with the largest share of the step "
+                        "(HIP events on the work stream inside the timed region); `limiter` names what the PMC counters show "
+                        "bounds it, with that roof in `valu` / `mfma` (DESIGN.md section 4)",
+                "stages": per_stage}
         elapsed = R["elapsed"]
+        ms_step = elapsed / args.steps * 1e3
         out = {
             "metric": "ORB keypoints/sec end-to-end (extract + match), %dx%d %d-level" % (w, h, cfg["levels"]),
             "value": R["kp_total"] * args.steps / elapsed,
             "unit": "keypoints/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": ms_step, "timed_region_ms": elapsed * 1e3,
             "higher_is_better": True, "scaling": m["scaling"], "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": m["workload"] + (" [RGB8 input, conversion fused]" if args.rgb else ""),
@@ -570,8 +711,10 @@ def main():
                        "scene": ("dense: 800 rectangles of 6..32 px per 640x480 of area + noise (fills the feature budget)"
                                  if args.scene == "dense" else
                                  "survey: SURVEY.md 8d generator, 96 rectangles up to a fifth of the frame + -3..3 noise"),
-                       "distinct_frames_per_rank": int(len(base)), "prewarm_steps": args.prewarm,
+                       "distinct_frames_per_rank": int(len(base)) * max(args.rotate, 1), "rotate": args.rotate,
+                       "prewarm_steps": state["prewarm"],
                        "frames_per_gpu_per_step": B, "frames_per_step": R["frames_total"],
+                       "resident_input_bytes_per_gpu": int(B) * w * h * (3 if args.rgb else 1) * max(args.rotate, 1),
                        "keypoints_per_frame": R["kp_total"] / max(R["frames_total"], 1),
                        "collective": (("RCCL (liborbfe_dist.so: grouped ncclSend/ncclRecv, %s) gather of 52-byte keypoint "
                                        "records + counts to rank 0 inside the timed region, overlapped with the next step"
@@ -580,14 +723,33 @@ def main():
                                       else "RCCL all-reduce(MAX) of the per-cell keys (liborbfe_dist.so)" if (args.mode == "c5" and multi)
                                       else "none in the data path; barrier + timing reductions only")},
             "frames_per_s": R["frames_total"] * args.steps / elapsed,
-            "matcher_gpairs_per_s": (R["pairs_local"] / (stages["match"] * 1e-3) / 1e9) if stages["match"] > 0 else None,
+            # descriptor pairs compared per second: only where the matcher really examines every pair (the cell-indexed
+            # windowed forms look at ~10 candidates per query; nA * nB would overstate them ~200x)
+            "matcher_gpairs_per_s": ((R["pairs_local"] / (stages["match"] * 1e-3) / 1e9)
+                                     if stages["match"] > 0 and disp.get("match_examines") == "all_pairs" else None),
+            "matcher_examines": disp.get("match_examines"),
             "matcher_pairs_per_step": R["pairs_total"],
             "stage_ms": stages,
-            "path_hbm": {"algorithmic_bytes_per_frame": ab["frame"],
-                         "achieved_GBps": ab["frame"] * B / (ms_extract * 1e-3) / 1e9,
-                         "frac_of_8TBps": ab["frame"] * B / (ms_extract * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+            # whole path against the HBM roofline: algorithmic bytes of extraction + matching per step / the WHOLE step
+            "path_hbm": {"algorithmic_bytes_per_frame": ab["frame"] + ab["match"],
+                         "achieved_GBps": (ab["frame"] + ab["match"]) * B / (ms_step * 1e-3) / 1e9,
+                         "frac_of_8TBps": (ab["frame"] + ab["match"]) * B / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         "frac_of_6.29TBps_measured_copy": (ab["frame"] + ab["match"]) * B / (ms_step * 1e-3) / 1e9 / 6290.0,
+                         "time": "ms_per_step (the whole step, matcher included; rank 0's bytes / the max-over-ranks time)"},
             "roofline": roof,
         }
+        if multi:
+            # what the gather moves, so that the first real multi-GPU run explains itself: xGMI is point to point, every
+            # non-root rank ships its block over its own link to the root (7 links x ~153 GB/s peak per GPU)
+            rec_bytes = (int(R["counts"].sum()) if args.exact_gather else B * cap) * 52 + 4 * B
+            out["gather"] = {"form": "exact" if args.exact_gather else "fixed_stride",
+                             "bytes_shipped_per_nonroot_rank_per_step": rec_bytes if use_gather else 0,
+                             "root_ingress_bytes_per_step": rec_bytes * (world - 1) if use_gather else 0,
+                             "per_link_GBps_needed_at_this_step_time": (rec_bytes / (ms_step * 1e-3) / 1e9) if use_gather else 0.0,
+                             "xgmi_link_peak_GBps": 153.0, "links_per_gpu": 7,
+                             "note": "fixed stride ships cap records per frame whatever the counts; the root's own block is written "
+                                     "in place (no copy).  Hardware status: the world > 1 branch of liborbfe_dist.so has not run on "
+                                     "a multi-GPU node of the build pool (world = 1 and gloo rehearsals only)" }
         out.update(extras)
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(base, args.mode)

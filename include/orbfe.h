@@ -323,6 +323,11 @@ int orbfe_memcpy_d2h(void *dst, const void *d_src, size_t bytes, orbfe_stream_t 
 int orbfe_memcpy_h2d(void *d_dst, const void *src, size_t bytes, orbfe_stream_t stream);
 int orbfe_stream_sync(orbfe_stream_t stream);
 int orbfe_version(void);
+/* Which kernels the batch calls run for this context, call size and matcher mode, as
+ * "pyramid=...;detect=...;describe=...;match=...;match_examines=all_pairs|window_cells" (the library picks the
+ * describe and match kernels by keypoint density, call size and window; bench.py labels its stages from this
+ * instead of repeating the conditions).  Host-side only. */
+int orbfe_dispatch_info(const orbfe_ctx *ctx, int n_frames, int mode, int window, char *buf, size_t size);
 
 #ifdef __cplusplus
 }

@@ -270,6 +270,17 @@ pyramid_fused_kernel(DeviceGeom g, uint8_t *__restrict__ pyr, const uint8_t *__r
 //   D  strict 3x3 maximum test on the positives only; winners atomicMax their nms_key()
 //      into the cell (LDS for cells >= 4 px, global for smaller cells)
 // ------------------------------------------------------------------------------------
+// Profiling aid (tools/phase_counters.sh): -DORBFE_DETECT_STOP_AFTER=n ends detect_tile_kernel after phase n
+// (1 = A tile load, 2 = B compass + compaction, 3 = C ring test), -DORBFE_DESCRIBE_STOP_AFTER=n the tile describe
+// kernel (1 = staging + keypoint list, 2 = moments, 3 = angles).  Results are then WRONG; the builds exist so
+// that PMC passes can attribute instructions and stalls to phases.  0 = the product.
+#ifndef ORBFE_DETECT_STOP_AFTER
+#define ORBFE_DETECT_STOP_AFTER 0
+#endif
+#ifndef ORBFE_DESCRIBE_STOP_AFTER
+#define ORBFE_DESCRIBE_STOP_AFTER 0
+#endif
+
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 __device__ inline us2 U2(uint32_t v) { return __builtin_bit_cast(us2, v); }
 __device__ inline uint32_t U1(us2 v) { return __builtin_bit_cast(uint32_t, v); }
@@ -358,8 +369,11 @@ __device__ inline int fast_score_packed(const uint8_t *p, uint32_t t2, int arc, 
     const uint32_t bright = (ub & 0xFFu) | ((ub >> 16) << 8), dark = (ud & 0xFFu) | ((ud >> 16) << 8);
     if (arc == 0) {
         if (!(lut[bright] | lut[dark])) return 0;
-    } else if (!(orbfe_has_arc(bright, arc) | orbfe_has_arc(dark, arc))) {
-        return 0;
+    } else {
+        // a pixel is never both brighter and darker, so the two masks are disjoint and only one of them can hold
+        // >= arc (>= 9 of 16) ones at all: ONE arc test, on the mask that has the population for it
+        const uint32_t m = __popc(bright) >= arc ? bright : dark;
+        if (!orbfe_has_arc(m, arc)) return 0;
     }
     const uint32_t xb = U1(sb), xd = U1(sd);
     const int rb = (int)((xb & 0xFFFFu) + (xb >> 16)), rd = (int)((xd & 0xFFFFu) + (xd >> 16));
@@ -479,6 +493,7 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
     if (lds_cells)
         for (int i = tid; i < ncx * ncy; i += 256) s_key[i] = 0u;
     __syncthreads();
+    if (ORBFE_DETECT_STOP_AFTER == 1) return;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint16_t *q1 = s_q1[wv], *q2 = s_q1[wv];
 
@@ -556,6 +571,10 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
     // (no block barrier: each wave consumes only its own queue; LDS ops of a wave are in order)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if (ORBFE_DETECT_STOP_AFTER == 2) {
+        if (n1 == 12345) cellkey[0] = q1[lane]; // keeps the queue alive
+        return;
+    }
 
     // ---- C: full ring test on the wave's candidates
     int n2 = 0;
@@ -577,6 +596,10 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
         n2 += (int)__popcll(m);
     }
     __syncthreads(); // every wave's scores are in s_sc
+    if (ORBFE_DETECT_STOP_AFTER == 3) {
+        if (n2 == 12345) cellkey[0] = s_sc[tid] + q2[lane];
+        return;
+    }
 
     if (STAGE && st.resp[l]) { // the tile's part of the caller's response map, zeros included
         float *rp = st.resp[l];
@@ -1294,6 +1317,10 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
         const int nkp = s_nkp;
         if (DL) cursor = s_cursor;
         if (nkp == 0) return; // uniform: no (further) keypoint in this tile
+        if (ORBFE_DESCRIBE_STOP_AFTER == 1) {
+            if (nkp == 12345) records[0].x = (float)s_tile[tid];
+            return;
+        }
         if (first) {
             // ---- border tiles: zero what the moments exclude / what lies outside the image: rows gy <= 0 and
             //      gy >= H, columns gx <= 0 and gx >= W (only the strips concerned are touched)
@@ -1374,6 +1401,10 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
             }
         }
         __syncthreads();
+        if (ORBFE_DESCRIBE_STOP_AFTER == 2) {
+            if (nkp == 12345) records[0].x = (float)s_mom[tid & 127];
+            return;
+        }
         // ---- phase B: one lane per keypoint: atan2f and the steering cos / sin, ONCE per pass
         if (wv == 0 && lane < nkp) {
             const float ang = orbfe_atan2f((float)s_mom[2 * lane + 1], (float)s_mom[2 * lane]);
@@ -1384,6 +1415,10 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
             s_sin[lane] = sb;
         }
         __syncthreads();
+        if (ORBFE_DESCRIBE_STOP_AFTER == 3) {
+            if (nkp == 12345) records[0].x = s_ang[tid & 63] + s_cos[tid & 63] + s_sin[tid & 63];
+            return;
+        }
         // ---- phase C: descriptors + records, keypoints dealt round-robin to the waves
         for (int j = wv; j < nkp; j += 4) { // uniform
             const uint32_t xy = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_kxy[j]);
@@ -2042,6 +2077,27 @@ static unsigned long long capture_id_of(hipStream_t stream)
     return st == hipStreamCaptureStatusActive ? (id ? id : ~0ull - 1) : 0ull;
 }
 
+// ---- which kernels a call runs: ONE definition, used by the dispatch below and by orbfe_dispatch_info ----
+static bool describe_uses_patch(const orbfe_ctx *ctx, int n_frames)
+{
+    // (the tile kernel finds a cell's record through the 16-bit cell -> slot map, 0xFFFF = none: frames that can
+    // hold more than 65534 records take the patch kernel, which walks the 32-bit selection list)
+    return ctx->describe_patch == 2 || (ctx->describe_patch == 1 && (long long)n_frames * ctx->g.cap >= 32768) ||
+           ctx->g.cap > 65534;
+}
+enum MatchPath { kMatchRefWindow, kMatchRefLiteral, kMatchMfma, kMatchWindow256, kMatchValu256 };
+static MatchPath match_path(const orbfe_ctx *ctx, int n_frames, int mode, int window)
+{
+    const DeviceGeom &g = ctx->g;
+    const int wc = window >= 0 ? 2 * ((window + g.cell - 1) / g.cell) + 1 : 0; // cells per window edge, at most
+    const bool few_cells = window >= 0 && (long long)wc * wc * 4 <= (long long)g.K;
+    if (mode == 0)
+        return (ctx->d_bend && ctx->d_bd32 && n_frames <= ctx->cfg.max_batch && few_cells) ? kMatchRefWindow : kMatchRefLiteral;
+    if (window < 0 && ctx->d_mexp) return kMatchMfma;        // all candidates, <= 16384 per frame: matrix cores
+    if (ctx->d_bend && few_cells) return kMatchWindow256;    // a window that spans few cells: walk the cell index
+    return kMatchValu256;
+}
+
 #define CTX_FAIL(ctx, code, ...)                                                            \
     do {                                                                                    \
         format_error((ctx) ? (ctx)->err : nullptr, __VA_ARGS__);                            \
@@ -2367,10 +2423,7 @@ int orbfe_describe_batch(orbfe_ctx *ctx, int n_frames, orbfe_keypoint *d_records
     if (soa) so = *soa;
     DeviceScope dev(ctx->cfg.device);
     if (!dev.ok) CTX_FAIL(ctx, ORBFE_ERR_HIP, "describe_batch: hipSetDevice(%d) failed", ctx->cfg.device);
-    // (the tile kernel finds a cell's record through the 16-bit cell -> slot map, 0xFFFF = none: frames that can
-    // hold more than 65534 records take the patch kernel, which walks the 32-bit selection list)
-    const bool patch = ctx->describe_patch == 2 || (ctx->describe_patch == 1 && (long long)n_frames * g.cap >= 32768) ||
-                       g.cap > 65534;
+    const bool patch = describe_uses_patch(ctx, n_frames);
     if (so.d_pos || so.d_score || so.d_level || so.d_angle || so.d_desc || so.d_desc32)
         hipLaunchKernelGGL(select_kernel<true>, dim3(n_frames), dim3(kSelThreads), 0, S(stream), g, ctx->d_cellkey,
                            patch ? ctx->d_sel : nullptr, ctx->d_cellslot, ctx->d_selcount, d_counts, so);
@@ -2450,43 +2503,33 @@ int orbfe_match_pairs(orbfe_ctx *ctx, const orbfe_keypoint *d_records, const int
     DeviceScope dev(ctx->cfg.device);
     if (!dev.ok) CTX_FAIL(ctx, ORBFE_ERR_HIP, "match: hipSetDevice(%d) failed", ctx->cfg.device);
     dim3 grid((cap + 255) / 256, n_pairs), block(256);
-    if (mode == 0) {
-        const DeviceGeom &g = ctx->g;
-        const int wc = 2 * ((window + g.cell - 1) / g.cell) + 1; // cells per window edge, at most
-        if (ctx->d_bend && ctx->d_bd32 && n_frames <= ctx->cfg.max_batch && (long long)wc * wc * 4 <= (long long)g.K) {
-            const float inv_cell = 1.0f / (float)g.cell;
-            launch_match_bucket(d_records, d_counts, n_pairs, cap, first, stride, g, inv_cell, ctx->d_bend, ctx->d_bsorted,
-                                ctx->d_bd32, S(stream));
-            hipLaunchKernelGGL(match_window_ref_kernel, grid, block, 0, S(stream), d_records, d_counts, cap, first, stride,
-                               g.K, g.cells_x, g.cells_y, inv_cell, ctx->d_bend, ctx->d_bsorted, ctx->d_bd32, window,
-                               max_distance, d_idx, d_dist);
-        } else {
-            hipLaunchKernelGGL(match_batch_ref_kernel, grid, block, 0, S(stream), d_records, d_counts, cap, first, stride,
-                               (float)window, max_distance, d_idx, d_dist);
-        }
-    } else {
-        if (n_frames > ctx->cfg.max_batch)
-            CTX_FAIL(ctx, ORBFE_ERR_CAPACITY, "match: n_frames %d > max_batch %d", n_frames, ctx->cfg.max_batch);
-        if (window < 0 && ctx->d_mexp) { // all candidates, <= 16384 per frame: matrix cores
-            const int capP = ctx->cap_pad;
-            launch_match_mfma(d_records, d_counts, n_frames, n_pairs, first, stride, cap, capP, max_distance, ctx->d_mexp,
-                              ctx->d_mkey, d_idx, d_dist, S(stream));
-            CTX_LAUNCH_CHECK(ctx, "match");
-            return ORBFE_OK;
-        }
-        const DeviceGeom &g = ctx->g;
-        // a window that spans few cells: walk the cell index (a few candidates per query) instead of all pairs
-        const int wc = window >= 0 ? 2 * ((window + g.cell - 1) / g.cell) + 1 : 0; // cells per window edge, at most
-        if (window >= 0 && ctx->d_bend && (long long)wc * wc * 4 <= (long long)g.K) {
-            const float inv_cell = 1.0f / (float)g.cell; // exact: the cell is a power of two
-            launch_match_bucket(d_records, d_counts, n_pairs, cap, first, stride, g, inv_cell, ctx->d_bend, ctx->d_bsorted,
-                                (uint32_t *)nullptr, S(stream));
-            hipLaunchKernelGGL(match_window_kernel, grid, block, 0, S(stream), d_records, d_counts, cap, first, stride, g.K,
-                               g.cells_x, g.cells_y, inv_cell, ctx->d_bend, ctx->d_bsorted, window, max_distance, d_idx,
-                               d_dist);
-            CTX_LAUNCH_CHECK(ctx, "match");
-            return ORBFE_OK;
-        }
+    const DeviceGeom &g = ctx->g;
+    const float inv_cell = 1.0f / (float)g.cell; // exact: the cell is a power of two
+    if (mode == 1 && n_frames > ctx->cfg.max_batch)
+        CTX_FAIL(ctx, ORBFE_ERR_CAPACITY, "match: n_frames %d > max_batch %d", n_frames, ctx->cfg.max_batch);
+    switch (match_path(ctx, n_frames, mode, window)) {
+    case kMatchRefWindow:
+        launch_match_bucket(d_records, d_counts, n_pairs, cap, first, stride, g, inv_cell, ctx->d_bend, ctx->d_bsorted,
+                            ctx->d_bd32, S(stream));
+        hipLaunchKernelGGL(match_window_ref_kernel, grid, block, 0, S(stream), d_records, d_counts, cap, first, stride,
+                           g.K, g.cells_x, g.cells_y, inv_cell, ctx->d_bend, ctx->d_bsorted, ctx->d_bd32, window,
+                           max_distance, d_idx, d_dist);
+        break;
+    case kMatchRefLiteral:
+        hipLaunchKernelGGL(match_batch_ref_kernel, grid, block, 0, S(stream), d_records, d_counts, cap, first, stride,
+                           (float)window, max_distance, d_idx, d_dist);
+        break;
+    case kMatchMfma:
+        launch_match_mfma(d_records, d_counts, n_frames, n_pairs, first, stride, cap, ctx->cap_pad, max_distance, ctx->d_mexp,
+                          ctx->d_mkey, d_idx, d_dist, S(stream));
+        break;
+    case kMatchWindow256:
+        launch_match_bucket(d_records, d_counts, n_pairs, cap, first, stride, g, inv_cell, ctx->d_bend, ctx->d_bsorted,
+                            (uint32_t *)nullptr, S(stream));
+        hipLaunchKernelGGL(match_window_kernel, grid, block, 0, S(stream), d_records, d_counts, cap, first, stride, g.K,
+                           g.cells_x, g.cells_y, inv_cell, ctx->d_bend, ctx->d_bsorted, window, max_distance, d_idx, d_dist);
+        break;
+    case kMatchValu256: {
         Desc8 *md = reinterpret_cast<Desc8 *>(ctx->d_mdesc);
         float2 *mp = reinterpret_cast<float2 *>(ctx->d_mpos);
         hipLaunchKernelGGL(match_gather_kernel, dim3((cap + 255) / 256, n_frames), block, 0, S(stream), d_records,
@@ -2497,8 +2540,32 @@ int orbfe_match_pairs(orbfe_ctx *ctx, const orbfe_keypoint *d_records, const int
         else
             hipLaunchKernelGGL(match_batch_256_kernel<false>, grid, block, 0, S(stream), md, mp, d_counts, cap, first,
                                stride, window, max_distance, d_idx, d_dist);
+        break;
+    }
     }
     CTX_LAUNCH_CHECK(ctx, "match");
+    return ORBFE_OK;
+}
+
+int orbfe_dispatch_info(const orbfe_ctx *ctx, int n_frames, int mode, int window, char *buf, size_t size)
+{
+    if (!ctx || !buf || size == 0 || n_frames < 1 || (mode != 0 && mode != 1)) return ORBFE_ERR_INVALID_ARG;
+    const DeviceGeom &g = ctx->g;
+    const char *desc = describe_uses_patch(ctx, n_frames) ? "describe_kernel" : "describe_tile_kernel";
+    const char *match = "";
+    switch (match_path(ctx, n_frames, mode, window)) {
+    case kMatchRefWindow: match = "match_bucket_kernel+match_window_ref_kernel"; break;
+    case kMatchRefLiteral: match = "match_batch_ref_kernel"; break;
+    case kMatchMfma: match = "match_expand_kernel+match_mfma_kernel"; break;
+    case kMatchWindow256: match = "match_bucket_kernel+match_window_kernel"; break;
+    case kMatchValu256: match = "match_gather_kernel+match_batch_256_kernel"; break;
+    }
+    snprintf(buf, size, "pyramid=%s;detect=detect_tile_kernel<%d>;describe=select_kernel+%s%s;match=%s;match_examines=%s",
+             (g.W % 4 == 0) ? "pyramid_fused_kernel" : "blur_batch_kernel+halfsample_batch_kernel", g.arc, desc,
+             g.descriptor_level ? "<descriptor_level>" : "", match,
+             match_path(ctx, n_frames, mode, window) == kMatchMfma || match_path(ctx, n_frames, mode, window) == kMatchValu256 ||
+                     match_path(ctx, n_frames, mode, window) == kMatchRefLiteral
+                 ? "all_pairs" : "window_cells");
     return ORBFE_OK;
 }
 

@@ -117,6 +117,7 @@ _SIGS = {
     "orbfe_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "orbfe_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "orbfe_stream_sync": (C.c_int, [C.c_void_p]),
+    "orbfe_dispatch_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
 }
 
 EXPORTS = tuple(_SIGS)  # every symbol include/orbfe.h declares
@@ -158,6 +159,21 @@ _POSE_SIGS = {  # include/orbfe_pose.h: f4, host code inside liborbfe.so
 POSE_EXPORTS = tuple(_POSE_SIGS)
 
 _lib = None
+
+
+def source_hash():
+    """sha256 over the sources liborbfe.so is built from (csrc/*.hip, *.hpp, *.cpp and include/*.h, by name): stamps
+    PMC-derived numbers (profiles/traffic.json) so that bench.py can tell when the kernels have changed since."""
+    import glob
+    import hashlib
+    root = os.path.dirname(PKG_DIR)
+    files = sorted(glob.glob(os.path.join(PKG_DIR, "csrc", "*.hip")) + glob.glob(os.path.join(PKG_DIR, "csrc", "*.hpp")) +
+                   glob.glob(os.path.join(PKG_DIR, "csrc", "*.cpp")) + glob.glob(os.path.join(root, "include", "*.h")))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
 
 
 def lib():
@@ -271,6 +287,12 @@ class Context:
                     d_dist=None, stream=0):
         check(lib().orbfe_match_pairs(self.handle, d_records, d_counts, n_frames, first, stride, mode, window,
                                       max_distance, d_idx, d_dist, stream), self.handle)
+
+    def dispatch_info(self, n_frames, mode=1, window=-1):
+        """{'pyramid': ..., 'detect': ..., 'describe': ..., 'match': ..., 'match_examines': ...}: the kernels a call runs."""
+        buf = C.create_string_buffer(512)
+        check(lib().orbfe_dispatch_info(self.handle, n_frames, mode, window, buf, 512), self.handle)
+        return dict(kv.split("=", 1) for kv in buf.value.decode().split(";"))
 
     def read_level(self, level, frame=0, stream=0):
         """Copy one pyramid level of one frame to a numpy array [h, w] (harness helper)."""

@@ -129,19 +129,29 @@ def test_descriptor_level_at_4k_and_many_levels(gpu, oracle_mod):
     assert len(np.unique(rec[0, :cnt[0]]["level"])) >= 3
 
 
-def test_descriptor_level_dense_coarse_tiles_take_several_passes(gpu, oracle_mod, monkeypatch):
-    """Uniform noise fills every cell; with 8-px cells a level-1 tile spans 256 cells and a level-3 tile up to 4096,
-    so the tile kernel's keypoint list (64 entries) is gathered in several passes.  Low FAST threshold so that the
-    (smoother) coarse levels still win a good share of the cells."""
+def _smooth_field(w, h, seed, factor):
+    """Uniform noise at 1 / factor of the resolution, bilinearly enlarged: weak corners on level 0, strong ones on the
+    coarse levels, so that the coarse levels win most cells (rectangles and pixel noise make level 0 win nearly all)."""
+    from scipy import ndimage
+    rng = np.random.default_rng(seed)
+    small = rng.integers(0, 256, (h // factor + 2, w // factor + 2)).astype(np.float32)
+    return np.clip(ndimage.zoom(small, factor, order=1)[:h, :w], 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("which", ["tile", "patch"])
+def test_descriptor_level_dense_coarse_tiles_take_several_passes(gpu, oracle_mod, monkeypatch, which):
+    """With 8-px cells a level-1 tile spans 256 cells, a level-2 tile 1024 and a level-3 tile up to 4096, so the tile
+    kernel's keypoint list (64 entries) is gathered in several passes when a coarse level wins many cells."""
     torch, orbfe = gpu
-    monkeypatch.setenv("ORBFE_DESCRIBE", "tile")
+    monkeypatch.setenv("ORBFE_DESCRIBE", which)
     w, h = 640, 480
     cfg = dict(levels=5, cell=8, min_arc=9, max_features=0, fast_threshold=5, descriptor_level=1)
-    frames = np.stack([synth.frame(w, h, 77, "uniform"), synth.frame(w, h, 78, "rects", **synth.DENSE)])
+    frames = np.stack([_smooth_field(w, h, 7, 8), _smooth_field(w, h, 8, 4), synth.frame(w, h, 77, "uniform")])
     ctx, rec, cnt, soa = _run_extract(torch, orbfe, frames, **cfg)
     total = _check_extract(oracle_mod, ctx, frames, rec, cnt, soa, **cfg)
     per_level = np.bincount(rec[0, :cnt[0]]["level"], minlength=4)
-    assert total > 5000 and per_level[1] > 64 and per_level[2] > 64, per_level
+    # 6 level-2 tiles and 2 level-3 tiles per frame: more than 64 keypoints per tile on each coarse level
+    assert total > 10000 and per_level[1] > 1500 and per_level[2] > 6 * 64 and per_level[3] > 2 * 64, per_level
 
 
 def test_fuzz_descriptor_level(gpu, oracle_mod):

@@ -20,7 +20,10 @@ rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_
     --output-format csv -d "$OUT/pmc_sq2" -o run -- $BENCH --steps 3 --warmup 1 > /dev/null 2>&1
 python3 "$ROOT/tools/pmc_summary.py" "$OUT/pmc_sq1" "$OUT/pmc_sq2" > "$OUT/pmc_sq.json"
 cd "$ROOT"
-python3 tools/make_traffic_json.py "$OUT/pmc_traffic.json" "$OUT/pmc_sq.json" ${MODE:-c2} "$OUT/traffic.json"
+python3 bench.py --mode ${MODE:-c2} --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_nocpu.json" 2> "$OUT/bench.err"
+cp "$OUT/bench_nocpu.json" "$OUT/bench.json"
+python3 tools/make_traffic_json.py "$OUT/pmc_traffic.json" "$OUT/pmc_sq.json" ${MODE:-c2} "$ROOT/profiles/traffic.json" $(python3 -c "import json;print(json.load(open('$OUT/bench.json'))['config']['frames_per_gpu_per_step'])")
+cp "$ROOT/profiles/traffic.json" "$OUT/traffic.json"  # (copy it back into profiles/ after the gpurun call and commit it)
 python3 bench.py --mode ${MODE:-c2} --steps 20 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"
 rm -rf "$OUT"/trace "$OUT"/pmc_fetch "$OUT"/pmc_write "$OUT"/pmc_sq1 "$OUT"/pmc_sq2
 ls -la "$OUT"

@@ -4,11 +4,20 @@ profiles/traffic.json: per bench stage, HBM-side bytes per launch and VALU wave-
 Corrections (MI355X_MICROARCH.md, HBM section; re-checked with tools/calib_copy on this pool: a
 512 MiB read reports FETCH_SIZE = 262146 KiB for 4-byte and for 16-byte loads):
 read bytes = FETCH_SIZE * 1024 * 2, write bytes = WRITE_SIZE * 1024.
-usage: make_traffic_json.py <pmc_traffic.json> <pmc_sq.json> <mode> <out.json>"""
+Every mode's entry is stamped with `batch` (frames per launch the passes were taken at) and `csrc_sha256`
+(orbfe.source_hash() of the kernels measured): bench.py scales the counts by its own batch and DROPS them when
+the sources have changed since ("if the kernels change and the PMC file is not refreshed, the
+number silently lies").
+usage: make_traffic_json.py <pmc_traffic.json> <pmc_sq.json> <mode> <out.json> [batch]"""
 import json
+import os
 import sys
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "jetracer-orbslam2_amd"))
+import orbfe  # noqa: E402  (source_hash only; nothing touches the GPU here)
+
 src, sq, mode, out = sys.argv[1:5]
+batch = int(sys.argv[5]) if len(sys.argv) > 5 else 256
 d = json.load(open(src))
 q = json.load(open(sq))
 
@@ -46,8 +55,14 @@ act = {s: sum(per_launch(q, p, lambda v: v.get("SQ_ACTIVE_INST_VALU", {}).get("a
 cyc = {s: sum(per_launch(q, p, lambda v: v.get("GRBM_GUI_ACTIVE", {}).get("avg", 0.0)) for p in ks) / 8.0 for s, ks in STAGES.items()}
 stages["valu_wave_instructions"] = valu
 stages["valu_pipe_busy"] = {s: (act[s] * 4.0 / 1024.0 / cyc[s] if cyc[s] else None) for s in STAGES}
+for name, counter in (("lds_bank_conflict_cycles", "SQ_LDS_BANK_CONFLICT"), ("salu_wave_instructions", "SQ_INSTS_SALU"),
+                      ("lds_wave_instructions", "SQ_INSTS_LDS"), ("mfma_wave_instructions", "SQ_INSTS_MFMA")):
+    stages[name] = {s: sum(per_launch(q, p, lambda v: v.get(counter, {}).get("avg", 0.0)) for p in ks) for s, ks in STAGES.items()}
+stages["gpu_cycles"] = cyc
+stages["batch"] = batch
+stages["csrc_sha256"] = orbfe.source_hash()
 allj[mode] = stages
-allj["_note"] = ("per stage launch (256 frames): HBM-side bytes from rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE "
+allj["_note"] = ("per stage launch (`batch` frames): HBM-side bytes from rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE "
                  "passes (reads doubled per the gfx950 correction), VALU wave-instructions (SQ_INSTS_VALU) and the fraction of "
                  "SIMD cycles with a VALU instruction executing (SQ_ACTIVE_INST_VALU x 4 / 1024 / cycles) from SQ passes")
 json.dump(allj, open(out, "w"), indent=1, sort_keys=True)
