@@ -212,10 +212,16 @@ __device__ inline void orb_describe_lds(const uint8_t *bytes, int c0, float a, f
         const float fpx = pt.x, fpy = pt.y, fqx = pt.z, fqy = pt.w;
         const float p1 = fpx * b, p2 = fpy * a, p3 = fpx * a, p4 = fpy * b;
         const float q1 = fqx * b, q2 = fqy * a, q3 = fqx * a, q4 = fqy * b;
-        const float prow = (p1 + p2) + M, pcol = (p3 - p4) + M;
-        const float qrow = (q1 + q2) + M, qcol = (q3 - q4) + M;
-        const float pa = __builtin_fmaf(prow - M, (float)PITCH, pcol);
-        const float qa = __builtin_fmaf(qrow - M, (float)PITCH, qcol);
+#ifdef ORBFE_DESCRIBE_MAGIC_ROUND
+        const float prow = ((p1 + p2) + M) - M, qrow = ((q1 + q2) + M) - M;
+#else
+        // the rounded row as an exact float in ONE instruction (v_rndne_f32 = round half to even, as the
+        // reference's __float2int_rn) instead of the add / subtract pair of the magic-constant form
+        const float prow = __builtin_rintf(p1 + p2), qrow = __builtin_rintf(q1 + q2);
+#endif
+        const float pcol = (p3 - p4) + M, qcol = (q3 - q4) + M;
+        const float pa = __builtin_fmaf(prow, (float)PITCH, pcol);
+        const float qa = __builtin_fmaf(qrow, (float)PITCH, qcol);
         const int t0 = bytes[__float_as_uint(pa) + cbias];
         const int t1 = bytes[__float_as_uint(qa) + cbias];
         d[r] = __ballot(t0 < t1);
