@@ -1226,7 +1226,11 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
     using G = TileGeom<R>;
     constexpr int P = G::kPitch;
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[G::kBytes + G::kPad];
-    __shared__ uint32_t s_kxy[64], s_kkey[64], s_kslot[64]; // the pass's keypoints: x | y << 16 (level coordinates), key, record slot
+    // the pass's keypoints: x | y << 16 (level coordinates); LDS byte offset of the keypoint inside the tile, bit 31 =
+    // all-zero descriptor (guard band, orb.cu:34); byte offset of its record in the frame's block.  Everything the
+    // descriptor loop needs per keypoint is precomputed here by one lane per keypoint: in that loop it was ~25 scalar
+    // instructions per keypoint, and the scalar unit issues one instruction per SIMD turn like the vector ALU
+    __shared__ uint32_t s_kxy[64], s_kc0[64], s_kslot[64];
     __shared__ int s_mom[128];                               // their moments: m10, m01
     __shared__ float s_ang[64], s_cos[64], s_sin[64];        // angle and steering (cos, sin)
     __shared__ int s_nkp, s_cursor;
@@ -1299,9 +1303,17 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
                     int sc, lv, x, y;
                     nms_decode(key, cx, cy, g.cell, &sc, &lv, &x, &y);
                     const int pos = cnt + (int)__popcll(m & ((1ull << lane) - 1ull));
-                    s_kxy[pos] = (uint32_t)(x >> l) | ((uint32_t)(y >> l) << 16);
-                    s_kkey[pos] = key;
-                    s_kslot[pos] = slot; // the cell index is recomputed from (x, y) where the SoA view needs it
+                    const int xl = x >> l, yl = y >> l;
+                    s_kxy[pos] = (uint32_t)xl | ((uint32_t)yl << 16);
+                    s_kc0[pos] = (uint32_t)((yl - oy) * P + xl - ox) | (orb_border_zero(xl, yl, W, H, g.angle_in_radians) ? 0x80000000u : 0u);
+                    s_kslot[pos] = slot * (uint32_t)sizeof(orbfe_keypoint); // (the SoA view recomputes the cell index from (x, y))
+                    // the record's head goes out from here, one lane per keypoint (in phase C it cost every keypoint's
+                    // wave 3 converts + 5 moves + 2 stores for one active lane); records keep level-0 coordinates
+                    uint32_t *rec = reinterpret_cast<uint32_t *>(records + (size_t)f * g.cap + slot);
+                    rec[0] = __float_as_uint((float)x);
+                    rec[1] = __float_as_uint((float)y);
+                    rec[2] = __float_as_uint((float)sc);
+                    rec[3] = (uint32_t)lv;
                 }
                 cnt += c;
                 cursor++;
@@ -1413,40 +1425,56 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
             s_ang[lane] = ang;
             s_cos[lane] = ca;
             s_sin[lane] = sb;
+            *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(records + (size_t)f * g.cap) + s_kslot[lane] + 16) = __float_as_uint(ang);
         }
         __syncthreads();
         if (ORBFE_DESCRIBE_STOP_AFTER == 3) {
             if (nkp == 12345) records[0].x = s_ang[tid & 63] + s_cos[tid & 63] + s_sin[tid & 63];
             return;
         }
-        // ---- phase C: descriptors + records, keypoints dealt round-robin to the waves
+        // ---- phase C: descriptors, keypoints dealt round-robin to the waves.  A keypoint's 256 bits are four
+        //      wave-uniform ballots, i.e. SGPR pairs: they go to the record by SCALAR stores (s_store_dwordx4: gfx950
+        //      still has them; tools/sstore_probe.hip checks them against vector stores into the same cache lines),
+        //      so the loop carries no vector instruction for the output at all
+        // (uniform, but the compiler does not see it through xcd_remap's division: pin it to SGPRs)
+        const uint64_t frv = reinterpret_cast<uint64_t>(records + (size_t)f * g.cap);
+        const char *frame_rec = reinterpret_cast<const char *>(
+            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)frv) |
+            ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(frv >> 32)) << 32));
+        // lane i holds keypoint i's four loop inputs; a keypoint's turn reads them with v_readlane (no LDS round
+        // trip in the loop).  The empty asm makes the pattern rows' loads complete HERE: the compiler otherwise
+        // waits for them inside the loop, four s_waitcnt per keypoint.
+        const uint32_t my_c0 = s_kc0[lane], my_roff = s_kslot[lane];
+        const uint32_t my_cos = __float_as_uint(s_cos[lane]), my_sin = __float_as_uint(s_sin[lane]);
+#pragma unroll
+        for (int r = 0; r < 4; r++) asm volatile("" ::"v"(pat[r].x), "v"(pat[r].y), "v"(pat[r].z), "v"(pat[r].w));
         for (int j = wv; j < nkp; j += 4) { // uniform
-            const uint32_t xy = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_kxy[j]);
-            const uint32_t key = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_kkey[j]);
-            const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_kslot[j]);
-            const float angle = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_ang[j])));
-            const float a = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_cos[j])));
-            const float b = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_sin[j])));
-            const int x = (int)(xy & 0xFFFFu), y = (int)(xy >> 16);
+            const uint32_t c0f = (uint32_t)__builtin_amdgcn_readlane((int)my_c0, j);
+            const uint32_t roff = (uint32_t)__builtin_amdgcn_readlane((int)my_roff, j);
+            const float a = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)my_cos, j));
+            const float b = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)my_sin, j));
+            const char *rec = frame_rec + roff;
             uint64_t d[4] = {0, 0, 0, 0};
-            if (!orb_border_zero(x, y, W, H, g.angle_in_radians))
-                orb_describe_lds<P>(s_tile, (y - oy) * P + x - ox, a, b, pat, d);
-            // every value is wave-uniform: lane 0 stores the 13 dwords of the record
+            if (!(c0f >> 31)) orb_describe_lds<P>(s_tile, (int)c0f, a, b, pat, d);
+            const u32x4 lo = {(uint32_t)d[0], (uint32_t)(d[0] >> 32), (uint32_t)d[1], (uint32_t)(d[1] >> 32)};
+            const u32x4 hi = {(uint32_t)d[2], (uint32_t)(d[2] >> 32), (uint32_t)d[3], (uint32_t)(d[3] >> 32)};
+#ifdef ORBFE_DESC_VECTOR_STORE // (A/B build: the stores as vector instructions of lane 0)
             if (lane == 0) {
-                const int score = (int)(key >> 15), level = 7 - (int)((key >> 12) & 7u);
-                const int X = x << l, Y = y << l; // records keep level-0 coordinates
-                uint32_t *rec = reinterpret_cast<uint32_t *>(records + (size_t)f * g.cap + slot);
-                rec[0] = __float_as_uint((float)X);
-                rec[1] = __float_as_uint((float)Y);
-                rec[2] = __float_as_uint((float)score);
-                rec[3] = (uint32_t)level;
-                rec[4] = __float_as_uint(angle);
+                uint32_t *rw = reinterpret_cast<uint32_t *>(const_cast<char *>(rec));
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    rec[5 + 2 * k] = (uint32_t)d[k];
-                    rec[6 + 2 * k] = (uint32_t)(d[k] >> 32);
+                    rw[5 + k] = lo[k];
+                    rw[9 + k] = hi[k];
                 }
-                if (SOA && (soa.d_angle || soa.d_desc32 || soa.d_desc)) { // (SOA: its own instantiation, as in select_kernel)
+            }
+#else
+            asm volatile("s_store_dwordx4 %0, %2, 0x14\n\ts_store_dwordx4 %1, %2, 0x24" ::"s"(lo), "s"(hi), "s"(rec) : "memory");
+#endif
+            if (SOA && (soa.d_angle || soa.d_desc32 || soa.d_desc)) { // (SOA: its own instantiation, as in select_kernel)
+                if (lane == 0) {
+                    const float angle = s_ang[j];
+                    const uint32_t xy = s_kxy[j];
+                    const int X = (int)(xy & 0xFFFFu) << l, Y = (int)(xy >> 16) << l;
                     const int cell = (Y / g.cell) * g.cells_x + X / g.cell;
                     const size_t o = (size_t)f * g.K + cell;
                     if (soa.d_angle) soa.d_angle[o] = angle;
@@ -1462,6 +1490,11 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
                 }
             }
         }
+#if !defined(ORBFE_DESC_VECTOR_STORE) && !defined(ORBFE_DESC_NO_WB)
+        // scalar stores sit in the scalar data cache until written back; the write-back covers only stores that
+        // have reached the cache, hence the wait
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb" ::: "memory");
+#endif
         if (!DL || cursor >= ngroups) break;
         __syncthreads(); // every wave is done with this pass's lists before the next gather overwrites them
     }
