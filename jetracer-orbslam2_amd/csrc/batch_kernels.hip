@@ -136,13 +136,14 @@ pyramid_fused_kernel(DeviceGeom g, uint8_t *__restrict__ pyr, const uint8_t *__r
 {
     __shared__ uint8_t s_l2[32 * 32], s_l3[16 * 16], s_l4[8 * 8], s_l5[4 * 4], s_l6[2 * 2];
     int f, tile;
-    xcd_remap(gridDim.x, gridDim.y, &f, &tile);
+    if (!frame_item(g, &f, &tile)) return;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int tid = threadIdx.x, cx = tid & 31, rg = tid >> 5;
     // by-product: the frame's cell keys are cleared for the detection that follows (saves the
     // memset launch of detect_batch); tile t clears the t-th slice
     {
-        const int per = (g.K + (int)gridDim.x - 1) / (int)gridDim.x;
+        const int n_tiles = (int)(g.grid8 ? gridDim.x >> 3 : gridDim.x); // tiles per frame (frame_grid)
+        const int per = (g.K + n_tiles - 1) / n_tiles;
         const int hi = (tile + 1) * per < g.K ? (tile + 1) * per : g.K;
         for (int i = tile * per + tid; i < hi; i += 256) cellkey[(size_t)f * g.K + i] = 0u;
     }
@@ -415,7 +416,7 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
     __shared__ uint32_t s_key[kMaxLdsCells];
 
     int f, tile_id;
-    xcd_remap(gridDim.x, gridDim.y, &f, &tile_id);
+    if (!frame_item(g, &f, &tile_id)) return;
     TileDesc td;
     if (STAGE) {
         int lvl = 0;
@@ -489,7 +490,8 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
     }
     const int c = g.cell >> l, lc = ilog2(c);
     const bool lds_cells = c >= 4;
-    const int ncx = kTileW / c > 0 ? kTileW / c : 1, ncy = kTileH / c > 0 ? kTileH / c : 1;
+    const int lnc = 6 - lc, ncx = 1 << lnc, ncy = 1 << lnc; // cells per tile edge: 64 / c, c = 1 .. 64 a power of two
+    static_assert(kTileW == 64 && kTileH == 64, "cells per tile edge as a shift");
     if (lds_cells)
         for (int i = tid; i < ncx * ncy; i += 256) s_key[i] = 0u;
     __syncthreads();
@@ -636,7 +638,7 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
     for (int i = tid; i < ncx * ncy; i += 256) {
         const uint32_t key = s_key[i];
         if (key == 0u) continue;
-        const int cx = x0 / c + i % ncx, cy = y0 / c + i / ncx;
+        const int cx = (x0 >> lc) + (i & (ncx - 1)), cy = (y0 >> lc) + (i >> lnc);
         if (cx < g.cells_x && cy < g.cells_y)
             atomicMax(&cellkey[(size_t)f * g.K + cy * g.cells_x + cx], key);
     }
@@ -965,7 +967,7 @@ describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__re
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // scalar: wave-uniform
     int f, blk;
-    xcd_remap(gridDim.x, gridDim.y, &f, &blk);
+    if (!frame_item(g, &f, &blk)) return;
     const int n = selcount[f];
     const int slot0 = (blk * 4 + wv) * kKpw; // wave-uniform
     if (slot0 >= n) return;
@@ -1238,7 +1240,7 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int f, tile;
-    xcd_remap(gridDim.x, gridDim.y, &f, &tile);
+    if (!frame_item(g, &f, &tile)) return;
     int l = 0, tx, ty;
     if (DL) {
         const TileDesc td = tiles[tile];
@@ -2093,6 +2095,15 @@ match_window_ref_kernel(const orbfe_keypoint *__restrict__ records, const int32_
 using namespace orbfe;
 
 static inline hipStream_t S(orbfe_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+// grid and geometry of a launch over (items per frame) x (n frames) for kernels that place themselves with frame_item()
+static inline dim3 frame_grid(int items, int n) { return n >= 8 ? dim3(8u * (unsigned)items, (unsigned)(n + 7) / 8u) : dim3(items, n); }
+static inline DeviceGeom with_frames(const DeviceGeom &g, int n)
+{
+    DeviceGeom r = g;
+    r.n_frames = n;
+    r.grid8 = n >= 8;
+    return r;
+}
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Identity of the graph capture `stream` is in (0 = not capturing).  The "cell keys are already
@@ -2337,11 +2348,11 @@ static int build_pyramid_impl(orbfe_ctx *ctx, const uint8_t *d_src, size_t pitch
     if (vec && g.W % 4 == 0) {
         const int tiles_x = (g.W + 127) / 128, tiles_y = (g.H + 127) / 128;
         if (rgb)
-            hipLaunchKernelGGL(pyramid_fused_kernel<true>, dim3(tiles_x * tiles_y, n_frames), dim3(256), 0, S(stream),
-                               g, ctx->d_pyr, d_src, (int)pitch, frame_stride, tiles_x, ctx->d_cellkey);
+            hipLaunchKernelGGL(pyramid_fused_kernel<true>, frame_grid(tiles_x * tiles_y, n_frames), dim3(256), 0, S(stream),
+                               with_frames(g, n_frames), ctx->d_pyr, d_src, (int)pitch, frame_stride, tiles_x, ctx->d_cellkey);
         else
-            hipLaunchKernelGGL(pyramid_fused_kernel<false>, dim3(tiles_x * tiles_y, n_frames), dim3(256), 0, S(stream),
-                               g, ctx->d_pyr, d_src, (int)pitch, frame_stride, tiles_x, ctx->d_cellkey);
+            hipLaunchKernelGGL(pyramid_fused_kernel<false>, frame_grid(tiles_x * tiles_y, n_frames), dim3(256), 0, S(stream),
+                               with_frames(g, n_frames), ctx->d_pyr, d_src, (int)pitch, frame_stride, tiles_x, ctx->d_cellkey);
         next_level = 8;
         // the fused kernel cleared these frames' cell keys; valid for a detect_batch issued next on
         // this stream in the same capture mode
@@ -2405,7 +2416,7 @@ int orbfe_detect_batch_shard(orbfe_ctx *ctx, int n_frames, int shard_index, int 
     // levels and of busy / empty image regions)
     const int n_mine = ctx->n_tiles > shard_index ? (ctx->n_tiles - shard_index + shard_count - 1) / shard_count : 0;
     if (n_mine > 0)
-        launch_detect_tiles(g, dim3(n_mine, n_frames), S(stream), ctx->d_pyr, ctx->d_tiles, ctx->d_cellkey, shard_index,
+        launch_detect_tiles(with_frames(g, n_frames), frame_grid(n_mine, n_frames), S(stream), ctx->d_pyr, ctx->d_tiles, ctx->d_cellkey, shard_index,
                             shard_count);
     CTX_LAUNCH_CHECK(ctx, "detect_batch");
     return ORBFE_OK;
@@ -2476,16 +2487,17 @@ int orbfe_describe_batch(orbfe_ctx *ctx, int n_frames, orbfe_keypoint *d_records
         if (g.descriptor_level) ORBFE_DESCRIBE_LAUNCH2(KERNEL, true, GRID, __VA_ARGS__);                            \
         else ORBFE_DESCRIBE_LAUNCH2(KERNEL, false, GRID, __VA_ARGS__);                                              \
     } while (0)
+    const DeviceGeom gl = with_frames(g, n_frames);
     if (patch) {
-        ORBFE_DESCRIBE_LAUNCH(describe_kernel, dim3((g.cap + 4 * kKpw - 1) / (4 * kKpw), n_frames), g, ctx->d_pyr, ctx->d_sel,
+        ORBFE_DESCRIBE_LAUNCH(describe_kernel, frame_grid((g.cap + 4 * kKpw - 1) / (4 * kKpw), n_frames), gl, ctx->d_pyr, ctx->d_sel,
                               ctx->d_selcount, ctx->d_momw, d_records, so);
     } else if (g.descriptor_level) { // one workgroup per detection tile: (level, 64x64 tile of that level)
         if (ctx->n_tiles > 0)
-            ORBFE_DESCRIBE_LAUNCH2(describe_tile_kernel, true, dim3(ctx->n_tiles, n_frames), g, ctx->d_pyr, ctx->d_cellkey,
+            ORBFE_DESCRIBE_LAUNCH2(describe_tile_kernel, true, frame_grid(ctx->n_tiles, n_frames), gl, ctx->d_pyr, ctx->d_cellkey,
                                    ctx->d_cellslot, ctx->d_momw_tile, 0, ctx->d_tiles, d_records, so);
     } else {
         const int tiles_x = (g.W + kDTile - 1) / kDTile, tiles_y = (g.H + kDTile - 1) / kDTile;
-        ORBFE_DESCRIBE_LAUNCH2(describe_tile_kernel, false, dim3(tiles_x * tiles_y, n_frames), g, ctx->d_pyr, ctx->d_cellkey,
+        ORBFE_DESCRIBE_LAUNCH2(describe_tile_kernel, false, frame_grid(tiles_x * tiles_y, n_frames), gl, ctx->d_pyr, ctx->d_cellkey,
                                ctx->d_cellslot, ctx->d_momw_tile, tiles_x, (const TileDesc *)nullptr, d_records, so);
     }
 #undef ORBFE_DESCRIBE_LAUNCH2

@@ -88,6 +88,23 @@ __device__ inline void xcd_remap(int items, int n_frames, int *frame, int *item)
     }
 }
 
+// The same placement without the division, for the kernels that take a DeviceGeom: the host launches
+// frame_grid(items, n) = (8 * items, ceil(n / 8)) blocks, so that blockIdx.x & 7 is the XCD the block lands on and
+// also the frame's index inside its group of 8; frames past n (last row only) return false.  Fewer than 8 frames:
+// the plain (items, n) grid.  xcd_remap's runtime division was ~40 scalar instructions per wave, and the scalar unit
+// issues once per SIMD turn like the vector ALU.
+__device__ inline bool frame_item(const DeviceGeom &g, int *frame, int *item)
+{
+    if (g.grid8) {
+        *frame = blockIdx.y * 8 + (blockIdx.x & 7);
+        *item = blockIdx.x >> 3;
+        return *frame < g.n_frames;
+    }
+    *frame = blockIdx.y;
+    *item = blockIdx.x;
+    return true;
+}
+
 // f1  RGB8 -> gray, src/cuda/cuda_RGB_to_Grayscale.cu:10-23: floor((B*0.07 + G*0.72 + R*0.21) + 0.5)
 // evaluated in double, left to right, without contraction (see oracle_rgb_to_grayscale).
 __device__ inline uint32_t rgb_to_gray1(uint32_t r, uint32_t g, uint32_t b)

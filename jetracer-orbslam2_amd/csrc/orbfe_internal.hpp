@@ -142,6 +142,9 @@ struct DeviceGeom { // passed by value to kernels
     int max_features;
     int angle_in_radians;
     int descriptor_level; // EXT iv: describe on the keypoint's own pyramid level
+    // per launch (with_frames): frames in this launch, and whether the grid is the 8-frames-per-row form of
+    // frame_item() (device_common.hpp)
+    int n_frames, grid8;
     size_t frame_stride;
     LevelInfo lv[kMaxLevels];
 };
