@@ -295,47 +295,68 @@ constexpr int kScW = kTileW + 2, kScH = kTileH + 2; // 66 x 66 score tile (1-px 
 constexpr int kScPitch = kScW + 2;                   // 68
 constexpr int kMaxLdsCells = (kTileW / 4) * (kTileH / 4);
 
-// candidate flags of 4 horizontally adjacent pixels -> bit i = pixel i may be a corner.
+// ---- compass pre-test on the four pixels of a dword AT ONCE, bytes in place (round 3).  Rounds 1-2 unpacked the
+// bytes into pairs of 16-bit lanes for v_pk_min/max/sub_u16: 50 instructions per dword, 27 of them at the packed
+// (4-cycle) rate.  Here every step is a full-rate 32-bit instruction (v_add / v_sub / v_and / v_or and the 3-input
+// v_bitop3_b32, 2.76 cycles: tools/valu_rate5.hip), 43 per dword.
+//   byte-wise a > b, result in bit 7 of each byte:  t = (b | H) - (a & L)  never borrows across bytes and its
+//   bit 7 says a_low7 <= b_low7;  a > b  =  (a7 & ~b7) | (~(a7 ^ b7) & ~t7)  -- one v_bitop3 (table 0x71).
+//   thresholds: s = (c + t) mod 256 with ovf = c > 255 - t (then no pixel can be brighter), d = (c - t) mod 256 with
+//   unf = c < t (then none can be darker); any t in 1..254.
+// Result: bit 8 i + 7 set <=> pixel i of the dword may be a corner; other bits clear.
+constexpr uint32_t kH8 = 0x80808080u, kL7 = 0x7F7F7F7Fu;
+#define ORBFE_BITOP3(a, b, c, tbl) __builtin_amdgcn_bitop3_b32((a), (b), (c), (tbl))
+constexpr int kGT = 0x71;    // (a & ~b) | (~(a ^ b) & ~c)
+constexpr int kXor3 = 0x96;  // a ^ b ^ c
+constexpr int kOrAnd = 0xA8; // (a | b) & c
+constexpr int kAndNotAnd = 0x20; // a & ~b & c
+constexpr int kAndOr = 0xEA; // (a & b) | c
+struct CompassConst { // wave-uniform, from the threshold
+    uint32_t T, TL, T7, nT7, K, KH;
+};
+__device__ inline CompassConst compass_const(int threshold)
+{
+    const uint32_t T = (uint32_t)threshold * 0x01010101u, K = (uint32_t)(255 - threshold) * 0x01010101u;
+    return CompassConst{T, T & kL7, T & kH8, ~T & kH8, K, K | kH8};
+}
 // MODE 0: arcs 9..11, MODE 1: arc >= 12 (closed forms, below); MODE 2: the reference's own opposite-pair
 // prechecks (fast.cu:98-124), literally -- the ring test runs iff (W or E is not similar to the centre) and
 // (N or S is not similar): the only form that is valid for an ARBITRARY corner table (stage API).
 template <int MODE>
-__device__ inline uint32_t compass4(uint32_t C, uint32_t Wd, uint32_t Ed, uint32_t Nd, uint32_t Sd, uint32_t t2)
+__device__ inline uint32_t compass4(uint32_t C, uint32_t Wd, uint32_t Ed, uint32_t Nd, uint32_t Sd, const CompassConst &k)
 {
-    uint32_t out = 0;
-#pragma unroll
-    for (int h = 0; h < 2; h++) { // h = 0: bytes 0,2 (pixels 0,2); h = 1: bytes 1,3 (pixels 1,3)
-        // bytes 0,2 (h = 0: one v_and) or 1,3 (h = 1: one v_perm) of a dword as two 16-bit lanes
-        auto lanes = [h](uint32_t x) { return U2(h ? __builtin_amdgcn_perm(0u, x, 0x0C030C01u) : (x & 0x00FF00FFu)); };
-        const us2 c = lanes(C), w = lanes(Wd), e = lanes(Ed), n = lanes(Nd), s = lanes(Sd);
-        const us2 hi = c + U2(t2), lo = ssub(c, U2(t2));
-        uint32_t f;
-        if (MODE == 2) {
-            // not similar: v > c + t or v < c - t (lo saturates at 0, where "darker" is impossible)
-            auto nonsim = [&](us2 v) { return U1(ssub(v, hi)) | U1(ssub(lo, v)); };
-            uint32_t fh = nonsim(w) | nonsim(e), fv = nonsim(n) | nonsim(s);
-            asm("v_pk_min_u16 %0, %1, %2" : "=v"(fh) : "v"(fh), "v"(0x00010001u));
-            asm("v_pk_min_u16 %0, %1, %2" : "=v"(fv) : "v"(fv), "v"(0x00010001u));
-            f = fh & fv;
-        } else {
-            const us2 a = pmax(n, s), b = pmin(n, s), cc = pmax(e, w), d = pmin(e, w);
-            const us2 m1 = pmin(a, cc), m2 = pmax(b, d);
-            // arc >= 12 (MODE 1): 3 of the 4 compass pixels lie in the arc, so the 3rd largest must be brighter
-            // or the 3rd smallest (= 2nd largest) darker.  arc 9..11: the arc leaves at most 7 contiguous ring
-            // pixels out, so it holds one pixel of EVERY opposite pair: max(N,S) and max(E,W) both brighter
-            // (m1), or min(N,S) and min(E,W) both darker (m2) -- tighter than "2 of 4" and two ops less
-            us2 bv = m1, dv = m2;
-            if (MODE == 1) {
-                bv = pmin(m1, m2);
-                dv = pmax(m1, m2);
-            }
-            f = U1(ssub(bv, hi)) | U1(ssub(lo, dv)); // 16-bit lane != 0 <=> candidate
-            asm("v_pk_min_u16 %0, %1, %2" : "=v"(f) : "v"(f), "v"(0x00010001u)); // lanes -> 0 / 1
-        }
-        out |= f << h; // h = 0: bits 0 and 16 (pixels 0, 2); h = 1: bits 1 and 17 (pixels 1, 3)
+    const uint32_t cL = C & kL7, cH = C | kH8, u = C & kH8;
+    // brighter side
+    const uint32_t ovf = ORBFE_BITOP3(C, k.K, k.KH - cL, kGT);          // c > 255 - t
+    const uint32_t s = ORBFE_BITOP3(cL + k.TL, u, k.T7, kXor3);         // (c + t) mod 256
+    const uint32_t sH = s | kH8;
+    // darker side
+    const uint32_t z = cH - k.TL;
+    const uint32_t unf = ORBFE_BITOP3(k.T, C, z, kGT);                   // t > c
+    const uint32_t d = ORBFE_BITOP3(z, u, k.nT7, kXor3);                // (c - t) mod 256
+    const uint32_t dL = d & kL7;
+    auto brighter = [&](uint32_t v) { return ORBFE_BITOP3(v, s, sH - (v & kL7), kGT); }; // v > s
+    auto darker = [&](uint32_t v) { return ORBFE_BITOP3(d, v, (v | kH8) - dL, kGT); };   // d > v
+    const uint32_t bN = brighter(Nd), bS = brighter(Sd), bE = brighter(Ed), bW = brighter(Wd);
+    const uint32_t dN = darker(Nd), dS = darker(Sd), dE = darker(Ed), dW = darker(Wd);
+    uint32_t br, dk;
+    if (MODE == 0) {
+        // an arc of >= 9 leaves at most 7 contiguous ring pixels out, so it holds one pixel of EVERY opposite pair:
+        // (N or S) and (E or W) brighter, or the same darker
+        br = ORBFE_BITOP3(bE, bW, bN | bS, kOrAnd);
+        dk = ORBFE_BITOP3(dE, dW, dN | dS, kOrAnd);
+    } else if (MODE == 1) {
+        // arc >= 12: three of the four compass pixels lie in the arc
+        br = ORBFE_BITOP3(bN & bS, bE | bW, bE & bW & (bN | bS), kAndOr);
+        dk = ORBFE_BITOP3(dN & dS, dE | dW, dE & dW & (dN | dS), kAndOr);
+    } else {
+        // not similar = brighter or darker; (W or E not similar) and (N or S not similar).  The overflow / underflow
+        // masks apply per polarity, so they are folded in before the polarities mix.
+        const uint32_t nsv = ORBFE_BITOP3(bN | bS, ovf, ORBFE_BITOP3(dN | dS, unf, kH8, kAndNotAnd), 0xBA /* (a & ~b) | c */);
+        const uint32_t nsh = ORBFE_BITOP3(bE | bW, ovf, ORBFE_BITOP3(dE | dW, unf, kH8, kAndNotAnd), 0xBA);
+        return nsv & nsh & kH8;
     }
-    out = (out | (out >> 14)) & 0xFu; // bit i = pixel i
-    return out;
+    return ORBFE_BITOP3(br, ovf, kH8, kAndNotAnd) | ORBFE_BITOP3(dk, unf, kH8, kAndNotAnd);
 }
 
 // FAST score (0 = not a corner) of the pixel at LDS byte pointer p, two ring pixels per op.
@@ -354,8 +375,8 @@ __device__ inline int fast_score_packed(const uint8_t *p, uint32_t t2, int arc, 
         const uint32_t v1 = p[ring_dy(i + 8) * kPxW + ring_dx(i + 8)];
         const us2 v = U2(v0 | (v1 << 16));
         const us2 ab = ssub(v, hi), ad = ssub(lo, v); // score terms v - (c+t), (c-t) - v, or 0
-        sb += ab;
-        sd += ad;
+        sb = U2(U1(sb) + U1(ab)); // 8 terms <= 255 per 16-bit lane: no carry between the lanes, so a full-rate v_add_u32
+        sd = U2(U1(sd) + U1(ad));
         // mask = mask * 2 + (term != 0), as v_pk_min_u16 + v_pk_mad_u16.  Inline asm because hipcc
         // rewrites min(x, 1) into per-half compare + select chains (3x the instructions).
         uint32_t fb, fd, nb, nd;
@@ -412,7 +433,7 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
     static_assert(32 + 2 * kScH <= 256, "halo trip must fit one block");
     // (r << 7) | px.  The positives queue q2 lives IN PLACE in q1: its write index never passes
     // the read index (positives so far <= candidates consumed), same wave, in-order LDS.
-    __shared__ uint16_t s_q1[4][kQ1];
+    __shared__ uint16_t s_q1[4][64 + kQ1]; // one dump halfword per lane (phase B's branch-free compaction), then the queue
     __shared__ uint32_t s_key[kMaxLdsCells];
 
     int f, tile_id;
@@ -497,78 +518,102 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
     __syncthreads();
     if (ORBFE_DETECT_STOP_AFTER == 1) return;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    uint16_t *q1 = s_q1[wv], *q2 = s_q1[wv];
+    uint16_t *q1 = s_q1[wv] + 64, *q2 = s_q1[wv] + 64;
 
     // ---- B: compass pre-test, 4 pixels per lane; score-tile row r <-> image y0 - 1 + r,
     //         pixel-tile column px <-> image x0 - 4 + px
     const uint32_t t2 = (uint32_t)g.threshold * 0x00010001u;
+    const CompassConst ck = compass_const(g.threshold);
     constexpr int kCompass = ARC == 0 ? 2 : (ARC >= 12 ? 1 : 0);
     int n1 = 0; // wave-uniform fill level of q1
     // Task = one dword group q (pixels px = 4q .. 4q+3) of score row r.  The first kMainTrips
-    // trips cover the tile proper (rows 1..kTileH, groups 1..16, 16 rows per trip: no division in
-    // the mapping); the last trip the 1-pixel halo ring (rows 0 and kScH-1, and the single pixels
-    // px = 3 / px = 68 of every row).
-    // `inner` tiles (no image border inside the score tile) skip the per-pixel range tests.
+    // trips cover the tile proper (rows 1..kTileH, groups 1..16, 16 rows per trip: the lane keeps its group, so
+    // the column masks are formed once); the last trip the 1-pixel halo ring (rows 0 and kScH-1, and the single
+    // pixels px = 3 / px = 68 of every row).  A trip's four flags sit in bits 7, 15, 23, 31; trip t's word is
+    // shifted right by t, so that ONE word holds all 20 flags of the lane: bit 8 i + 7 - t = (trip t, pixel i).
+    // `inner` tiles (no image border inside the score tile) skip the range tests.
     const bool inner = x0 >= 4 && x0 + kTileW < W - 3 && y0 >= 4 && y0 + kTileH < H - 3;
-    static_assert(kTrips * 4 <= 32, "one flag word per lane");
-    uint32_t allflags = 0, ebase[kTrips]; // 4 candidate flags per trip; (r << 7) | 4 q of the trip's dword group
+    static_assert(kTrips <= 8, "one flag word per lane");
+    // pixels i of a group starting at image column xb that are >= 3 from the left / right border, as flag bits
+    auto colmask = [&](int xb) {
+        int lo_i = 3 - xb, hi_i = W - 3 - xb; // pixel i valid iff lo_i <= i < hi_i
+        lo_i = lo_i < 0 ? 0 : (lo_i > 4 ? 4 : lo_i);
+        hi_i = hi_i < 0 ? 0 : (hi_i > 4 ? 4 : hi_i);
+        const uint32_t m4 = hi_i > lo_i ? (((1u << hi_i) - 1u) & ~((1u << lo_i) - 1u)) : 0u;
+        return ((m4 * 0x00204081u) & 0x01010101u) << 7; // bit i -> bit 8 i + 7
+    };
+    uint32_t allflags = 0;
+    {
+        const int q = (tid & 15) + 1, r0 = (tid >> 4) + 1;
+        const uint32_t cm = inner ? kH8 : colmask(x0 - 4 + 4 * q);
+        const uint32_t *row = s_px32 + (r0 + 3) * kPxDw + q;
 #pragma unroll
-    for (int trip = 0; trip < kTrips; trip++) {
-        uint32_t flags = 0;
+        for (int trip = 0; trip < kMainTrips; trip++, row += 16 * kPxDw) {
+            const uint32_t C = row[0], L = row[-1], Rr = row[1];
+            const uint32_t Nd = row[-3 * kPxDw], Sd = row[3 * kPxDw];
+            const uint32_t Wd = __builtin_amdgcn_alignbyte(C, L, 1);  // bytes x-3 of the 4 pixels
+            const uint32_t Ed = __builtin_amdgcn_alignbyte(Rr, C, 3); // bytes x+3
+            uint32_t f = compass4<kCompass>(C, Wd, Ed, Nd, Sd, ck) & cm;
+            if (!inner) {
+                const int y = y0 - 1 + r0 + 16 * trip;
+                f = (y >= 3 && y < H - 3) ? f : 0u;
+            }
+            allflags |= f >> trip;
+        }
+    }
+    uint32_t ehalo = 0; // (r << 7) | 4 q of the halo trip's group
+    if (tid < 32 + 2 * kScH) { // waves 0..2
         int r, q;
-        uint32_t mask = 0xFu; // pixels of the group that belong to the score tile
-        if (trip < kMainTrips) {
-            q = (tid & 15) + 1;
-            r = (tid >> 4) + 1 + 16 * trip;
-        } else if (tid < 32) {
+        uint32_t mask;
+        if (tid < 32) {
             q = (tid & 15) + 1;
             r = tid < 16 ? 0 : kScH - 1;
+            mask = kH8;
         } else if (tid < 32 + kScH) {
             q = 0;
             r = tid - 32;
-            mask = 0x8u; // px = 3
-        } else if (tid < 32 + 2 * kScH) {
+            mask = 0x80000000u; // px = 3
+        } else {
             q = kPxDw - 1;
             r = tid - 32 - kScH;
-            mask = 0x1u; // px = 68
-        } else {
-            q = 0;
-            r = 0;
-            mask = 0u;
+            mask = 0x00000080u; // px = 68
         }
-        if (!inner && mask) {
+        if (!inner) {
             const int y = y0 - 1 + r;
-            const int xb = x0 - 4 + 4 * q;
-            int lo_i = 3 - xb, hi_i = W - 3 - xb; // pixel i valid iff lo_i <= i < hi_i
-            lo_i = lo_i < 0 ? 0 : (lo_i > 4 ? 4 : lo_i);
-            hi_i = hi_i < 0 ? 0 : (hi_i > 4 ? 4 : hi_i);
-            mask &= (y >= 3 && y < H - 3 && hi_i > lo_i) ? (((1u << hi_i) - 1u) & ~((1u << lo_i) - 1u)) : 0u;
+            mask &= (y >= 3 && y < H - 3) ? colmask(x0 - 4 + 4 * q) : 0u;
         }
-        if (mask) {
-            const uint32_t *row = s_px32 + (r + 3) * kPxDw;
-            const uint32_t C = row[q];
-            const uint32_t L = q > 0 ? row[q - 1] : 0u, Rr = q < kPxDw - 1 ? row[q + 1] : 0u;
-            const uint32_t Nd = row[q - 3 * kPxDw], Sd = row[q + 3 * kPxDw];
-            const uint32_t Wd = __builtin_amdgcn_alignbyte(C, L, 1);  // bytes x-3 of the 4 pixels
-            const uint32_t Ed = __builtin_amdgcn_alignbyte(Rr, C, 3); // bytes x+3
-            flags = compass4<kCompass>(C, Wd, Ed, Nd, Sd, t2) & mask;
-        }
-        allflags |= flags << (4 * trip);
-        ebase[trip] = (uint32_t)((r << 7) | (4 * q));
+        const uint32_t *row = s_px32 + (r + 3) * kPxDw;
+        const uint32_t C = row[q];
+        const uint32_t L = q > 0 ? row[q - 1] : 0u, Rr = q < kPxDw - 1 ? row[q + 1] : 0u;
+        const uint32_t Nd = row[q - 3 * kPxDw], Sd = row[q + 3 * kPxDw];
+        const uint32_t Wd = __builtin_amdgcn_alignbyte(C, L, 1);
+        const uint32_t Ed = __builtin_amdgcn_alignbyte(Rr, C, 3);
+        allflags |= (compass4<kCompass>(C, Wd, Ed, Nd, Sd, ck) & mask) >> kMainTrips;
+        ehalo = (uint32_t)((r << 7) | (4 * q));
     }
     // wave-level compaction, ONCE for all trips: a lane's candidates take consecutive slots starting at
-    // the exclusive prefix of the per-lane counts (one DPP scan per tile and wave instead of one per trip:
-    // the scan, not the test, was a third of this phase's instructions)
+    // the exclusive prefix of the per-lane counts (one DPP scan per tile and wave).  The 20 stores carry no
+    // branch and no EXEC change (each was v_and + v_cmp + s_and_saveexec + ... + s_or: 40 scalar instructions per
+    // wave): a clear flag sends the store to the lane's own dump halfword behind the queue.
     {
         const int cnt = __popc(allflags);
         const int incl = wave_incl_scan_i32(cnt);
         n1 = __builtin_amdgcn_readlane(incl, 63);
-        int slot = incl - cnt;
+        // byte offsets inside the wave's array: the dump halfwords lie BELOW the queue, so that next slot - dump is a
+        // small positive number and flag * delta is one v_mad_u32_u24
+        const uint32_t dump = (uint32_t)lane * 2u;
+        uint32_t delta = 128u + (uint32_t)(incl - cnt) * 2u - dump;
+        uint8_t *qb = reinterpret_cast<uint8_t *>(s_q1[wv]);
+        const uint32_t emain = (uint32_t)((((tid >> 4) + 1) << 7) | (4 * ((tid & 15) + 1)));
 #pragma unroll
         for (int trip = 0; trip < kTrips; trip++)
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-                if (allflags >> (4 * trip + i) & 1u) q1[slot++] = (uint16_t)(ebase[trip] + i);
+            for (int i = 0; i < 4; i++) {
+                const uint32_t bit = (allflags >> (8 * i + 7 - trip)) & 1u;
+                const uint32_t e = trip < kMainTrips ? emain + (uint32_t)((16 * trip) << 7) + (uint32_t)i : ehalo + (uint32_t)i;
+                *reinterpret_cast<uint16_t *>(qb + dump + __umul24(bit, delta)) = (uint16_t)e;
+                delta += 2u * bit;
+            }
     }
     // (no block barrier: each wave consumes only its own queue; LDS ops of a wave are in order)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
