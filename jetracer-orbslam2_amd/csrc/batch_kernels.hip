@@ -460,7 +460,9 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
     //         with one carry, so there is no division; tiles that lie inside the image (with their
     //         halo) skip the range tests.
     {
-        const bool all_in = x0 >= 4 && x0 + kTileW + 4 <= P && y0 >= 4 && y0 + kTileH + 4 <= H; // uniform
+        // batch path: the context's pyramid has guard bands, every tile loads without range tests.  Stage API
+        // (caller-owned levels): only tiles that lie inside the image with their halo do.
+        const bool all_in = !STAGE || (x0 >= 4 && x0 + kTileW + 4 <= P && y0 >= 4 && y0 + kTileH + 4 <= H); // uniform
         int r = tid / kPxDw, q = tid - r * kPxDw;
         uint32_t off = (uint32_t)(__mul24(y0 - 4 + r, P) + x0 - 4 + 4 * q); // wraps harmlessly when unused
         const uint32_t dstep = (uint32_t)((256 / kPxDw) * P + 4 * (256 % kPxDw));
@@ -474,7 +476,8 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
 #pragma unroll
             for (int t = 0; t < kLoadTrips; t++) {
                 const bool in = 256 * (t + 1) <= kPxH * kPxDw || 256 * t + tid < kPxH * kPxDw;
-                v[t] = *reinterpret_cast<const uint32_t *>(img + (in ? off : off0));
+                // (int): rows above the level's first one give a NEGATIVE offset (guard band / previous level)
+                v[t] = *reinterpret_cast<const uint32_t *>(img + (int)(in ? off : off0));
                 off += dstep;
                 q += 256 % kPxDw;
                 if (q >= kPxDw) { // carry into the next row
@@ -2284,8 +2287,13 @@ int orbfe_create(const orbfe_config *cfg, orbfe_ctx **out)
     ctx->n_tiles = (int)tiles.size();
 
     const size_t B = (size_t)cfg->max_batch;
-    hipError_t e = hipMalloc((void **)&ctx->d_pyr, B * g.frame_stride + 256);
-    if (e == hipSuccess) e = hipMemset(ctx->d_pyr, 0, B * g.frame_stride + 256);
+    // guard bands: a detection tile reads rows y0 - 4 .. y0 + 67 and columns x0 - 4 .. x0 + 67 of its level without
+    // range tests (what lies outside the image is never used: the validity masks of phase B); inside the buffer that
+    // is a neighbouring level or frame, at its two ends it is these bands
+    const size_t guard = align_up((size_t)(kTileH + 8) * (size_t)g.lv[0].pitch + 256, 256);
+    hipError_t e = hipMalloc((void **)&ctx->d_pyr_alloc, B * g.frame_stride + 2 * guard);
+    if (e == hipSuccess) e = hipMemset(ctx->d_pyr_alloc, 0, B * g.frame_stride + 2 * guard);
+    if (e == hipSuccess) ctx->d_pyr = ctx->d_pyr_alloc + guard;
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_cellkey, B * g.K * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_sel, B * g.cap * sizeof(uint4));
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_selcount, B * sizeof(int32_t));
@@ -2337,7 +2345,7 @@ int orbfe_create(const orbfe_config *cfg, orbfe_ctx **out)
 void orbfe_destroy(orbfe_ctx *ctx)
 {
     if (!ctx) return;
-    if (ctx->d_pyr) (void)hipFree(ctx->d_pyr);
+    if (ctx->d_pyr_alloc) (void)hipFree(ctx->d_pyr_alloc);
     if (ctx->d_cellkey) (void)hipFree(ctx->d_cellkey);
     if (ctx->d_sel) (void)hipFree(ctx->d_sel);
     if (ctx->d_selcount) (void)hipFree(ctx->d_selcount);

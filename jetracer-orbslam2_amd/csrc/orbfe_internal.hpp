@@ -192,6 +192,8 @@ struct orbfe_ctx {
     orbfe_config cfg;
     orbfe::DeviceGeom g;
     uint8_t *d_pyr = nullptr;       // [max_batch][frame_stride]
+    uint8_t *d_pyr_alloc = nullptr; // the allocation: d_pyr lies kPyrGuardRows rows of level 0 inside it, and as many follow
+                                    // the last frame, so that detect's tile loads need no range tests (batch_kernels.hip 4.2 A)
     uint32_t *d_cellkey = nullptr;  // [max_batch][K]
     uint4 *d_sel = nullptr;         // [max_batch][cap] selected keypoints in cell order: {cell, x | y << 16, key, 0}
     int32_t *d_selcount = nullptr;  // [max_batch]
