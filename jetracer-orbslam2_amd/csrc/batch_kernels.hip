@@ -547,18 +547,23 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
     };
     uint32_t allflags = 0;
     {
-        const int q = (tid & 15) + 1, r0 = (tid >> 4) + 1;
+        // a lane's four trips are four ADJACENT rows (a 4 x 4 pixel block; the wave covers a band of 16 rows), so
+        // that the 64 consecutive queue entries of a ring-test batch are a compact patch of the tile: with rows 16
+        // apart per lane (rounds 1-2) a batch held the same columns of rows r, r + 16, r + 32, r + 48, and 16 rows
+        // of 18 dwords are a multiple of the 32 LDS banks -- systematic 4-way conflicts on all 17 ring reads
+        const int q = (tid & 15) + 1, r0 = 4 * (tid >> 4) + 1;
         const uint32_t cm = inner ? kH8 : colmask(x0 - 4 + 4 * q);
         const uint32_t *row = s_px32 + (r0 + 3) * kPxDw + q;
+        static_assert(kMainTrips == 4, "a lane's trips are the rows of its 4 x 4 block");
 #pragma unroll
-        for (int trip = 0; trip < kMainTrips; trip++, row += 16 * kPxDw) {
+        for (int trip = 0; trip < kMainTrips; trip++, row += kPxDw) {
             const uint32_t C = row[0], L = row[-1], Rr = row[1];
             const uint32_t Nd = row[-3 * kPxDw], Sd = row[3 * kPxDw];
             const uint32_t Wd = __builtin_amdgcn_alignbyte(C, L, 1);  // bytes x-3 of the 4 pixels
             const uint32_t Ed = __builtin_amdgcn_alignbyte(Rr, C, 3); // bytes x+3
             uint32_t f = compass4<kCompass>(C, Wd, Ed, Nd, Sd, ck) & cm;
             if (!inner) {
-                const int y = y0 - 1 + r0 + 16 * trip;
+                const int y = y0 - 1 + r0 + trip;
                 f = (y >= 3 && y < H - 3) ? f : 0u;
             }
             allflags |= f >> trip;
@@ -607,13 +612,13 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
         const uint32_t dump = (uint32_t)lane * 2u;
         uint32_t delta = 128u + (uint32_t)(incl - cnt) * 2u - dump;
         uint8_t *qb = reinterpret_cast<uint8_t *>(s_q1[wv]);
-        const uint32_t emain = (uint32_t)((((tid >> 4) + 1) << 7) | (4 * ((tid & 15) + 1)));
+        const uint32_t emain = (uint32_t)(((4 * (tid >> 4) + 1) << 7) | (4 * ((tid & 15) + 1)));
 #pragma unroll
         for (int trip = 0; trip < kTrips; trip++)
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const uint32_t bit = (allflags >> (8 * i + 7 - trip)) & 1u;
-                const uint32_t e = trip < kMainTrips ? emain + (uint32_t)((16 * trip) << 7) + (uint32_t)i : ehalo + (uint32_t)i;
+                const uint32_t e = trip < kMainTrips ? emain + (uint32_t)(trip << 7) + (uint32_t)i : ehalo + (uint32_t)i;
                 *reinterpret_cast<uint16_t *>(qb + dump + __umul24(bit, delta)) = (uint16_t)e;
                 delta += 2u * bit;
             }
@@ -667,10 +672,12 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
         const int r = e >> 7, px = e & 127;
         const uint16_t *q = &s_sc[r * kScPitch + px - 3];
         const int v = q[0];
-        const bool is_max = v > q[-kScPitch] && v > q[-kScPitch + 1] && v > q[1] &&
-                            v > q[kScPitch + 1] && v > q[kScPitch] && v > q[kScPitch - 1] &&
-                            v > q[-1] && v > q[-kScPitch - 1];
-        if (!is_max) continue;
+        // strictly greater than all 8 neighbours <=> greater than their maximum (three v_max3 and one v_max instead
+        // of eight compares chained by EXEC updates: the short-circuit form cost 16 scalar instructions per trip)
+        const int m0 = max(max((int)q[-kScPitch - 1], (int)q[-kScPitch]), (int)q[-kScPitch + 1]);
+        const int m1 = max(max((int)q[-1], (int)q[1]), (int)q[kScPitch - 1]);
+        const int m2 = max((int)q[kScPitch], (int)q[kScPitch + 1]);
+        if (v <= max(max(m0, m1), m2)) continue;
         const int rx = px - 4, ry = r - 1;
         const uint32_t key = nms_key(v, l, x0 + rx, y0 + ry, g.cell);
         if (lds_cells) {

@@ -51,7 +51,8 @@ __host__ __device__ inline NmsGeom nms_geom(int cell0, int level)
 {
     NmsGeom g;
     g.c = cell0 >> level;
-    int t = 128 / (g.c > 0 ? g.c : 1);
+    // 128 / c as a shift (c is a power of two, 1 .. 64: a runtime division costs ~40 instructions per workgroup)
+    int t = 128 >> (g.c > 0 ? 31 - __builtin_clz((unsigned)g.c) : 0);
     int m = t < g.c ? t : g.c;
     g.by = m > 1 ? m : 1;
     return g;
