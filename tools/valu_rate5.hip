@@ -59,6 +59,25 @@ KERNEL(k_cmp_sgpr, "v_cmp_lt_u32 s[20:21], %0, %8\n v_cmp_lt_u32 s[22:23], %1, %
 KERNEL(k_cmp_u16_sgpr, "v_cmp_lt_u16 s[20:21], %0, %8\n v_cmp_lt_u16 s[22:23], %1, %9\n v_cmp_lt_u16 s[24:25], %2, %10\n v_cmp_lt_u16 s[26:27], %3, %11\n v_cmp_lt_u16 s[20:21], %4, %8\n v_cmp_lt_u16 s[22:23], %5, %9\n v_cmp_lt_u16 s[24:25], %6, %10\n v_cmp_lt_u16 s[26:27], %7, %11")
 KERNEL(k_readfirstlane, "v_readfirstlane_b32 s20, %0\n v_readfirstlane_b32 s21, %1\n v_readfirstlane_b32 s22, %2\n v_readfirstlane_b32 s23, %3\n v_readfirstlane_b32 s24, %4\n v_readfirstlane_b32 s25, %5\n v_readfirstlane_b32 s26, %6\n v_readfirstlane_b32 s27, %7")
 KERNEL(k_dot4_u8, OP3("v_dot4_u32_u8", ""))
+// packed fp32 (64-bit register pairs): 8 independent chains of 2 floats
+typedef float f2 __attribute__((ext_vector_type(2)));
+#define KERNEL2(NAME, BODY)                                                                         \
+    __global__ void __launch_bounds__(256) NAME(uint32_t *out, int iters, uint32_t seed)            \
+    {                                                                                               \
+        f2 a0 = {(float)threadIdx.x, 1.f}, a1 = a0 * 3.f, a2 = a0 * 5.f, a3 = a0 * 7.f, t0 = {1.0001f, 0.9999f}, t1 = {0.5f, 0.25f}; \
+        for (int i = 0; i < iters; i++) {                                                           \
+            _Pragma("unroll") for (int k = 0; k < 16; k++)                                          \
+            {                                                                                       \
+                asm volatile(BODY : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(t0), "v"(t1));     \
+            }                                                                                       \
+        }                                                                                           \
+        const f2 r = a0 + a1 + a2 + a3;                                                             \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = __float_as_uint(r.x + r.y);                    \
+    }
+// 4 instructions per body, 16 bodies per iteration = 64 = 8 x the KERNEL macro's 8: same count per iteration as KERNEL
+KERNEL2(k_pk_mul_f32, "v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4")
+KERNEL2(k_pk_add_f32, "v_pk_add_f32 %0, %0, %5\n v_pk_add_f32 %1, %1, %5\n v_pk_add_f32 %2, %2, %5\n v_pk_add_f32 %3, %3, %5")
+KERNEL2(k_pk_fma_f32, "v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5")
 typedef void (*kern_t)(uint32_t *, int, uint32_t);
 static void run(const char *name, kern_t k, uint32_t *d)
 {
@@ -80,6 +99,6 @@ int main()
     R(k_add_u32); R(k_sub_u32); R(k_and_b32); R(k_or_b32); R(k_lshrrev); R(k_lshlrev); R(k_bitop3); R(k_and_or); R(k_or3); R(k_bfi);
     R(k_lshl_add); R(k_add3); R(k_xad); R(k_sad_u8); R(k_msad_u8); R(k_perm); R(k_alignbit); R(k_mul_u24); R(k_mad_u24); R(k_mul_lo);
     R(k_rndne); R(k_cvt_ub0); R(k_cvt_u32_f32); R(k_not); R(k_mov); R(k_mul_f32); R(k_fmac_f32); R(k_pk_add_u16);
-    R(k_max_u16); R(k_min_u32); R(k_cndmask); R(k_cmp_sgpr); R(k_cmp_u16_sgpr); R(k_readfirstlane); R(k_dot4_u8);
+    R(k_max_u16); R(k_min_u32); R(k_cndmask); R(k_cmp_sgpr); R(k_cmp_u16_sgpr); R(k_readfirstlane); R(k_dot4_u8); R(k_pk_mul_f32); R(k_pk_add_f32); R(k_pk_fma_f32);
     return 0;
 }
