@@ -230,3 +230,73 @@ def test_rccl_exact_gather_offsets_world1(gpu, oracle_mod):
     for f in (0, 1, 2, 3, 255, 256, 257, 299):
         assert got[o[f]:o[f] + cnt[f]].tobytes() == rec[f, :cnt[f]].tobytes()
     comm.close()
+
+
+# ------------------------------------------------------------------ round-3 kernel changes
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 11, 16, 23])
+def test_frame_counts_around_the_eight_frame_grid_rows(gpu, oracle_mod, n):
+    """pyramid / detect / describe place a block by (blockIdx.x & 7, blockIdx.y) in rows of 8 frames (frame_item,
+    device_common.hpp); the last row of a batch that is no multiple of 8 holds blocks without a frame.  Every frame
+    of every batch size must still equal the oracle, the SoA view included."""
+    torch, orbfe = gpu
+    w, h = 320, 240
+    base = synth.frames(w, h, 5, 700 + n, "rects", **synth.DENSE)
+    frames = base[np.arange(n) % 5]
+    cfg = dict(levels=4, cell=8, min_arc=9, max_features=300)
+    ctx, rec, cnt, soa = _run_extract(torch, orbfe, frames, **cfg)
+    assert _check_extract(oracle_mod, ctx, frames, rec, cnt, soa, **cfg) > 50 * n
+
+
+def test_context_reuse_clears_every_cell_key(gpu, oracle_mod):
+    """The pyramid kernel clears the frame's cell keys in slices, one per tile (it takes the number of tiles from the
+    grid: with the 8-frames-per-row grid a wrong divisor left most keys of a REUSED context uncleared).  Busy frames
+    first, then near-empty ones through the same context: the second result must not inherit a key."""
+    torch, orbfe = gpu
+    w, h, n = 640, 480, 16
+    busy = synth.frames(w, h, 4, 41, "rects", **synth.DENSE)[np.arange(n) % 4]
+    quiet = np.full((n, h, w), 128, np.uint8)
+    quiet[:, 200:232, 300:340] = 30  # one dark rectangle: a handful of corners
+    cfg = dict(levels=6)  # reference regime: cell 32, levels 0..5
+    ctx = orbfe.Context(w, h, max_batch=n, **cfg)
+    rec = torch.zeros(n * ctx.cap * 52, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(n, dtype=torch.int32, device="cuda")
+    ocfg = oracle_mod.make_config(w, h, levels=6)
+    for frames in (busy, quiet, busy):
+        d_in = dev(torch, frames)
+        ctx.extract(d_in.data_ptr(), w, w * h, n, rec.data_ptr(), cnt.data_ptr(), None, stream(torch))
+        torch.cuda.synchronize()
+        counts = cnt.cpu().numpy()
+        records = rec.cpu().numpy().view(orbfe.KEYPOINT_DTYPE).reshape(n, ctx.cap)
+        for f in (0, 1, 2, 3, n - 1):
+            ref = oracle_mod.extract_frame(frames[f], ocfg)
+            assert counts[f] == ref["count"]
+            assert records[f, :counts[f]].tobytes() == ref["records"].tobytes()
+    ctx.close()
+
+
+@pytest.mark.parametrize("thr", [1, 100, 127, 128, 200, 254])
+@pytest.mark.parametrize("arc", [9, 12])
+def test_compass_pretest_at_every_threshold_range(gpu, oracle_mod, thr, arc):
+    """The byte-wise compass pre-test (compass4, batch_kernels.hip) forms c + t and c - t modulo 256 with explicit
+    overflow / underflow masks; thresholds with the top bit set and sums that wrap are its corner cases.  Frames of
+    uniform noise and of saturated black / white blocks (c + t > 255, c - t < 0 on most pixels)."""
+    torch, orbfe = gpu
+    w, h = 256, 192
+    rng = np.random.default_rng(1000 + thr)
+    noise = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    blocks = (rng.integers(0, 2, (h // 8, w // 8), dtype=np.uint8) * 255).repeat(8, 0).repeat(8, 1)
+    blocks[::5, ::7] ^= 0x80
+    edge = np.where(rng.random((h, w)) < 0.5, 255 - rng.integers(0, 3, (h, w)), rng.integers(0, 3, (h, w))).astype(np.uint8)
+    frames = np.stack([noise, blocks, edge])
+    cfg = dict(levels=3, cell=8, min_arc=arc, fast_threshold=thr)
+    ctx, rec, cnt, soa = _run_extract(torch, orbfe, frames, **cfg)
+    _check_extract(oracle_mod, ctx, frames, rec, cnt, soa, **cfg)
+
+
+@pytest.mark.parametrize("thr", [1.0, 127.0, 128.0, 200.0])
+def test_stage_detect_prechecks_at_every_threshold_range(gpu, oracle_mod, thr):
+    """orbfe_detect's fused path runs the reference's own prechecks (fast.cu:98-124) in the byte-wise form
+    (compass4<2>): not similar = brighter or darker, each polarity masked by its own overflow / underflow."""
+    torch, orbfe = gpu
+    n = _detect_case(torch, orbfe, oracle_mod, 424, 240, 3, 9, thr, True, 0)
+    assert n > 0 or thr >= 127.0
