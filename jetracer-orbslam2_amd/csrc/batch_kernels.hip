@@ -282,6 +282,14 @@ pyramid_fused_kernel(DeviceGeom g, uint8_t *__restrict__ pyr, const uint8_t *__r
 #define ORBFE_DESCRIBE_STOP_AFTER 0
 #endif
 
+// entry i of the context's tile list (8 bytes, 8-byte aligned) through the constant address space: s_load_dwordx2
+static_assert(sizeof(TileDesc) == 8, "TileDesc is read as one 64-bit scalar load");
+__device__ inline TileDesc load_tile_desc(const TileDesc *tiles, int i)
+{
+    const uint64_t raw = reinterpret_cast<const __attribute__((address_space(4))) uint64_t *>(reinterpret_cast<uintptr_t>(tiles))[i];
+    return TileDesc{(int16_t)(raw & 0xFFFFu), (int16_t)((raw >> 16) & 0xFFFFu), (int16_t)((raw >> 32) & 0xFFFFu), 0};
+}
+
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 __device__ inline us2 U2(uint32_t v) { return __builtin_bit_cast(us2, v); }
 __device__ inline uint32_t U1(us2 v) { return __builtin_bit_cast(uint32_t, v); }
@@ -446,7 +454,10 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
         const int t = tile_id - st.first[lvl], tyy = t / st.tiles_x[lvl];
         td = TileDesc{(int16_t)lvl, (int16_t)(t - tyy * st.tiles_x[lvl]), (int16_t)tyy, 0};
     } else {
-        td = tiles[tile_first + tile_id * tile_step]; // shard: every tile_step-th tile
+        // shard: every tile_step-th tile.  The index is wave-uniform and the list is never written by a kernel: read it
+        // through the constant address space, i.e. with ONE s_load_dwordx2 (as a global load it was two vector loads
+        // and two v_readfirstlane at the head of every wave)
+        td = load_tile_desc(tiles, tile_first + tile_id * tile_step);
     }
     const int l = td.level;
     const int W = g.lv[l].w, H = g.lv[l].h, P = g.lv[l].pitch;
@@ -1298,7 +1309,7 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
     if (!frame_item(g, &f, &tile)) return;
     int l = 0, tx, ty;
     if (DL) {
-        const TileDesc td = tiles[tile];
+        const TileDesc td = load_tile_desc(tiles, tile); // (scalar load, as in detect_tile_kernel)
         l = td.level;
         tx = td.tx;
         ty = td.ty;
