@@ -132,12 +132,12 @@ pyramid_tail_kernel(DeviceGeom g, uint8_t *__restrict__ pyr, int first_level)
 template <bool RGB>
 __global__ void __launch_bounds__(256)
 pyramid_fused_kernel(DeviceGeom g, uint8_t *__restrict__ pyr, const uint8_t *__restrict__ src, int src_pitch,
-                     size_t src_fstride, int tiles_x, uint32_t *__restrict__ cellkey)
+                     size_t src_fstride, int tiles_x, uint32_t tiles_x_magic, uint32_t *__restrict__ cellkey)
 {
     __shared__ uint8_t s_l2[32 * 32], s_l3[16 * 16], s_l4[8 * 8], s_l5[4 * 4], s_l6[2 * 2];
     int f, tile;
     if (!frame_item(g, &f, &tile)) return;
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int ty = div_by_magic(tile, tiles_x_magic), tx = tile - ty * tiles_x;
     const int tid = threadIdx.x, cx = tid & 31, rg = tid >> 5;
     // by-product: the frame's cell keys are cleared for the detection that follows (saves the
     // memset launch of detect_batch); tile t clears the t-th slice
@@ -1288,7 +1288,7 @@ static std::vector<int8_t> make_tile_moment_weights()
 template <int R, bool SOA, bool DL>
 __global__ void __launch_bounds__(256)
 describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32_t *__restrict__ cellkey,
-                     const uint16_t *__restrict__ cellslot, const uint4 *__restrict__ momw, int tiles_x,
+                     const uint16_t *__restrict__ cellslot, const uint4 *__restrict__ momw, int tiles_x, uint32_t tiles_x_magic,
                      const TileDesc *__restrict__ tiles, orbfe_keypoint *__restrict__ records, orbfe_soa soa)
 {
     using G = TileGeom<R>;
@@ -1314,7 +1314,7 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
         tx = td.tx;
         ty = td.ty;
     } else {
-        ty = tile / tiles_x;
+        ty = div_by_magic(tile, tiles_x_magic);
         tx = tile - ty * tiles_x;
     }
     const int W = g.lv[l].w, H = g.lv[l].h; // the sampled level (l = 0 unless DL)
@@ -2162,6 +2162,9 @@ using namespace orbfe;
 
 static inline hipStream_t S(orbfe_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 // grid and geometry of a launch over (items per frame) x (n frames) for kernels that place themselves with frame_item()
+// n / d for 0 <= n < 65536 and 1 <= d <= 256 as one s_mul_hi_u32 (device_common.hpp div_by_magic): magic = ceil(2^32 / d),
+// 0 for d == 1; exact because n * (magic * d - 2^32) < 65536 * 256 < 2^32
+static inline uint32_t magic_of(int d) { return d <= 1 ? 0u : (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d); }
 static inline dim3 frame_grid(int items, int n) { return n >= 8 ? dim3(8u * (unsigned)items, (unsigned)(n + 7) / 8u) : dim3(items, n); }
 static inline DeviceGeom with_frames(const DeviceGeom &g, int n)
 {
@@ -2420,10 +2423,10 @@ static int build_pyramid_impl(orbfe_ctx *ctx, const uint8_t *d_src, size_t pitch
         const int tiles_x = (g.W + 127) / 128, tiles_y = (g.H + 127) / 128;
         if (rgb)
             hipLaunchKernelGGL(pyramid_fused_kernel<true>, frame_grid(tiles_x * tiles_y, n_frames), dim3(256), 0, S(stream),
-                               with_frames(g, n_frames), ctx->d_pyr, d_src, (int)pitch, frame_stride, tiles_x, ctx->d_cellkey);
+                               with_frames(g, n_frames), ctx->d_pyr, d_src, (int)pitch, frame_stride, tiles_x, magic_of(tiles_x), ctx->d_cellkey);
         else
             hipLaunchKernelGGL(pyramid_fused_kernel<false>, frame_grid(tiles_x * tiles_y, n_frames), dim3(256), 0, S(stream),
-                               with_frames(g, n_frames), ctx->d_pyr, d_src, (int)pitch, frame_stride, tiles_x, ctx->d_cellkey);
+                               with_frames(g, n_frames), ctx->d_pyr, d_src, (int)pitch, frame_stride, tiles_x, magic_of(tiles_x), ctx->d_cellkey);
         next_level = 8;
         // the fused kernel cleared these frames' cell keys; valid for a detect_batch issued next on
         // this stream in the same capture mode
@@ -2565,11 +2568,11 @@ int orbfe_describe_batch(orbfe_ctx *ctx, int n_frames, orbfe_keypoint *d_records
     } else if (g.descriptor_level) { // one workgroup per detection tile: (level, 64x64 tile of that level)
         if (ctx->n_tiles > 0)
             ORBFE_DESCRIBE_LAUNCH2(describe_tile_kernel, true, frame_grid(ctx->n_tiles, n_frames), gl, ctx->d_pyr, ctx->d_cellkey,
-                                   ctx->d_cellslot, ctx->d_momw_tile, 0, ctx->d_tiles, d_records, so);
+                                   ctx->d_cellslot, ctx->d_momw_tile, 0, 0u, ctx->d_tiles, d_records, so);
     } else {
         const int tiles_x = (g.W + kDTile - 1) / kDTile, tiles_y = (g.H + kDTile - 1) / kDTile;
         ORBFE_DESCRIBE_LAUNCH2(describe_tile_kernel, false, frame_grid(tiles_x * tiles_y, n_frames), gl, ctx->d_pyr, ctx->d_cellkey,
-                               ctx->d_cellslot, ctx->d_momw_tile, tiles_x, (const TileDesc *)nullptr, d_records, so);
+                               ctx->d_cellslot, ctx->d_momw_tile, tiles_x, magic_of(tiles_x), (const TileDesc *)nullptr, d_records, so);
     }
 #undef ORBFE_DESCRIBE_LAUNCH2
 #undef ORBFE_DESCRIBE_LAUNCH

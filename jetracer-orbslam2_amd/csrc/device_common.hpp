@@ -105,6 +105,9 @@ __device__ inline bool frame_item(const DeviceGeom &g, int *frame, int *item)
     return true;
 }
 
+// tile index -> tile row without a runtime division: the host passes magic_of(tiles_x) (batch_kernels.hip)
+__device__ inline int div_by_magic(int n, uint32_t magic) { return magic ? (int)__umulhi((uint32_t)n, magic) : n; }
+
 // f1  RGB8 -> gray, src/cuda/cuda_RGB_to_Grayscale.cu:10-23: floor((B*0.07 + G*0.72 + R*0.21) + 0.5)
 // evaluated in double, left to right, without contraction (see oracle_rgb_to_grayscale).
 __device__ inline uint32_t rgb_to_gray1(uint32_t r, uint32_t g, uint32_t b)
