@@ -441,7 +441,12 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
     static_assert(32 + 2 * kScH <= 256, "halo trip must fit one block");
     // (r << 7) | px.  The positives queue q2 lives IN PLACE in q1: its write index never passes
     // the read index (positives so far <= candidates consumed), same wave, in-order LDS.
-    __shared__ uint16_t s_q1[4][64 + kQ1]; // one dump halfword per lane (phase B's branch-free compaction), then the queue
+    // ONE candidate queue per workgroup (round 3; rounds 1-2 had one per wave): 256 dump halfwords (one per thread,
+    // phase B's branch-free compaction), then up to 4 * kQ1 entries.  A wave reserves its run with one LDS atomic, and
+    // the ring test walks the queue in batches of 64 dealt round-robin to the waves: the last, partly filled batch
+    // exists once per tile instead of once per wave (3.36 -> 3.02 batches per wave on the bench scenes).
+    __shared__ uint16_t s_q[256 + 4 * kQ1];
+    __shared__ int s_qcount;
     __shared__ uint32_t s_key[kMaxLdsCells];
 
     int f, tile_id;
@@ -529,10 +534,13 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
     static_assert(kTileW == 64 && kTileH == 64, "cells per tile edge as a shift");
     if (lds_cells)
         for (int i = tid; i < ncx * ncy; i += 256) s_key[i] = 0u;
+    if (tid == 0) s_qcount = 0;
     __syncthreads();
     if (ORBFE_DETECT_STOP_AFTER == 1) return;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    uint16_t *q1 = s_q1[wv] + 64, *q2 = s_q1[wv] + 64;
+    uint16_t *q1 = s_q + 256; // the queue proper
+    // slot of this wave's p-th positive: in place, inside the batches the wave itself has consumed (64 (wv + 4 j) ..)
+    auto q2slot = [wv](int p) { return ((p >> 6) << 8) + (wv << 6) + (p & 63); };
 
     // ---- B: compass pre-test, 4 pixels per lane; score-tile row r <-> image y0 - 1 + r,
     //         pixel-tile column px <-> image x0 - 4 + px
@@ -618,11 +626,14 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
         const int cnt = __popc(allflags);
         const int incl = wave_incl_scan_i32(cnt);
         n1 = __builtin_amdgcn_readlane(incl, 63);
-        // byte offsets inside the wave's array: the dump halfwords lie BELOW the queue, so that next slot - dump is a
-        // small positive number and flag * delta is one v_mad_u32_u24
-        const uint32_t dump = (uint32_t)lane * 2u;
-        uint32_t delta = 128u + (uint32_t)(incl - cnt) * 2u - dump;
-        uint8_t *qb = reinterpret_cast<uint8_t *>(s_q1[wv]);
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_qcount, n1); // the wave's run in the workgroup's queue
+        base = __builtin_amdgcn_readfirstlane(base);
+        // byte offsets inside s_q: the dump halfwords lie BELOW the queue, so that next slot - dump is a small
+        // positive number and flag * delta is one v_mad_u32_u24
+        const uint32_t dump = (uint32_t)tid * 2u;
+        uint32_t delta = 512u + (uint32_t)(base + incl - cnt) * 2u - dump;
+        uint8_t *qb = reinterpret_cast<uint8_t *>(s_q);
         const uint32_t emain = (uint32_t)(((4 * (tid >> 4) + 1) << 7) | (4 * ((tid & 15) + 1)));
 #pragma unroll
         for (int trip = 0; trip < kTrips; trip++)
@@ -634,21 +645,20 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
                 delta += 2u * bit;
             }
     }
-    // (no block barrier: each wave consumes only its own queue; LDS ops of a wave are in order)
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads(); // the queue is complete
+    const int nq = s_qcount;
     if (ORBFE_DETECT_STOP_AFTER == 2) {
-        if (n1 == 12345) cellkey[0] = q1[lane]; // keeps the queue alive
+        if (nq == 12345) cellkey[0] = q1[lane]; // keeps the queue alive
         return;
     }
 
-    // ---- C: full ring test on the wave's candidates
+    // ---- C: full ring test, batches of 64 candidates dealt round-robin to the waves
     int n2 = 0;
-    for (int i0 = 0; i0 < n1; i0 += 64) {
+    for (int i0 = 64 * wv; i0 < nq; i0 += 256) {
         const int i = i0 + lane;
         bool pos = false;
         int e = 0;
-        if (i < n1) {
+        if (i < nq) {
             e = q1[i];
             const int r = e >> 7, px = e & 127;
             const int sc = fast_score_packed(s_px + (r + 3) * kPxW + px, t2, ARC, st.lut);
@@ -658,12 +668,12 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
             }
         }
         const uint64_t m = __ballot(pos);
-        if (pos) q2[n2 + (int)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)e;
+        if (pos) q1[q2slot(n2 + (int)__popcll(m & ((1ull << lane) - 1ull)))] = (uint16_t)e;
         n2 += (int)__popcll(m);
     }
     __syncthreads(); // every wave's scores are in s_sc
     if (ORBFE_DETECT_STOP_AFTER == 3) {
-        if (n2 == 12345) cellkey[0] = s_sc[tid] + q2[lane];
+        if (n2 == 12345) cellkey[0] = s_sc[tid] + q1[lane];
         return;
     }
 
@@ -679,7 +689,7 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
 
     // ---- D: strict 3x3 maximum on the positives, then the cell's maximum key
     for (int i = lane; i < n2; i += 64) {
-        const int e = q2[i];
+        const int e = q1[q2slot(i)];
         const int r = e >> 7, px = e & 127;
         const uint16_t *q = &s_sc[r * kScPitch + px - 3];
         const int v = q[0];
