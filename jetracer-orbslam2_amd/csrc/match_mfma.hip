@@ -129,16 +129,20 @@ match_mfma_kernel(const uint4 *__restrict__ mexp, const float *__restrict__ mkey
         const uint32_t ring_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)ring;
         const uint32_t lds16 = ring_lds + lane * 16, ldsk = ring_lds + (lane & 15) * 16; // this lane's read addresses
         const int T = wv < nBb ? (nBb - wv + 3) >> 2 : 0; // blocks of this wave
+        const uint32_t lane_off16 = (uint32_t)lane * 16u, lane_off4 = (uint32_t)(lane >> 2) * 4u;
         auto issue = [&](int s, int t) {
             int lb = wv + 4 * t;
             lb = lb < nBb ? lb : nBb - 1;
-            const uint4 *src = Eb + (size_t)lb * 128 + lane;
+            // uniform base + 32-bit lane offset: the SGPR-base form of the instruction, no 64-bit vector add
+            const char *src = reinterpret_cast<const char *>(Eb + (size_t)lb * 128) + lane_off16;
             unsigned char *dst = ring + s * kSlotBytes; // wave-uniform; lane L lands at dst + size * L
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 64),
-                                             (__attribute__((address_space(3))) void *)(dst + 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Kb + lb * 16 + (lane >> 2)),
+            // the instruction offset moves the global AND the LDS address (tools/dma_offset_probe.hip): the second
+            // kilobyte needs no second address pair and no second M0 write
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)dst, 16, 1024, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(Kb + lb * 16) + lane_off4),
                                              (__attribute__((address_space(3))) void *)(dst + 2048), 4, 0, 0);
         };
         // One step = TWO candidate blocks (slots s, s + 1; s even).  On this chip VALU issue does
