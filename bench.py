@@ -10,9 +10,10 @@ records) followed by the Hamming matcher.  Rank 0 prints ONE JSON line.
 Modes (BASELINE.json configs):
   c2   configs[1], the metric: 640x480 mono, 8-level pyramid, 2000 features/frame; here cell 8
        (4800 cells, detection on levels 0..3), FAST-9 t = 13, top-2000 by (score desc, cell asc),
-       256-bit brute-force matching t-1 -> t; 2048 frames per GPU per step (weak scaling; 2.5 GB of
+       256-bit brute-force matching t-1 -> t; 4096 frames per GPU per step (weak scaling; 5 GB of
        inputs, pyramids, records and matcher scratch resident in HBM, far beyond the 256 MB Infinity
-       Cache, so no step finds its data cached by the previous one; --batch 256 is round 1-2's size).
+       Cache, so no step finds its data cached by the previous one, and 20 steps are > 100 ms of GPU
+       work; --batch 256 is round 1-2's size).
   ref  the reference-parity configuration (cell 32, FAST-12, 6 levels, <= 300 keypoints, 32-bit
        windowed matcher) -- a parity case, not the metric.
   c3   configs[2]: RealSense-shaped stereo 848x480 pairs (right = left shifted 3 px + noise),
@@ -47,7 +48,7 @@ sys.path.insert(0, os.path.join(ROOT, "jetracer-orbslam2_amd"))
 
 EXT = dict(levels=8, cell=8, min_arc=9, max_features=2000)
 MODES = {
-    "c2": dict(width=640, height=480, cfg=EXT, match=dict(mode=1, window=-1, max_distance=256), batch=2048, stride=1,
+    "c2": dict(width=640, height=480, cfg=EXT, match=dict(mode=1, window=-1, max_distance=256), batch=4096, stride=1,
                scaling="weak",
                workload="640x480 mono, 8-level pyramid, 2000 features/frame (cell 8, FAST-9 t=13, top-2000), "
                         "256-bit brute-force match t-1->t"),
