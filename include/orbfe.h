@@ -328,6 +328,12 @@ int orbfe_version(void);
  * describe and match kernels by keypoint density, call size and window; bench.py labels its stages from this
  * instead of repeating the conditions).  Host-side only. */
 int orbfe_dispatch_info(const orbfe_ctx *ctx, int n_frames, int mode, int window, char *buf, size_t size);
+/* Exhaustive self-check of the orientation -> rotated-pattern table the tile describe kernel uses in the reference's
+ * degrees-as-radians regime (angle_in_radians = 0): for EVERY float orientation in [-pi, pi] (both
+ * signs, ~2.2e9 values) the table's 512 sample offsets are compared with the arithmetic of orb.cu:12-14, :42-46 as the
+ * oracle and the other kernels evaluate it.  Synchronous (~1 s on an MI355X); *n_mismatch must come back 0.  With
+ * angle_in_radians = 1 there is no table: *n_angles = 0. */
+int orbfe_selfcheck_steer_table(orbfe_ctx *ctx, unsigned long long *n_angles, unsigned long long *n_mismatch);
 
 #ifdef __cplusplus
 }

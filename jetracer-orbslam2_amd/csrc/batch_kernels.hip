@@ -290,6 +290,8 @@ __device__ inline TileDesc load_tile_desc(const TileDesc *tiles, int i)
     return TileDesc{(int16_t)(raw & 0xFFFFu), (int16_t)((raw >> 16) & 0xFFFFu), (int16_t)((raw >> 32) & 0xFFFFu), 0};
 }
 
+constexpr int kSteerMaxBreaks = 1024; // LDS copy of the steering table's break points in the tile describe kernel
+
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 __device__ inline us2 U2(uint32_t v) { return __builtin_bit_cast(us2, v); }
 __device__ inline uint32_t U1(us2 v) { return __builtin_bit_cast(uint32_t, v); }
@@ -1299,7 +1301,7 @@ template <int R, bool SOA, bool DL>
 __global__ void __launch_bounds__(256)
 describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32_t *__restrict__ cellkey,
                      const uint16_t *__restrict__ cellslot, const uint4 *__restrict__ momw, int tiles_x, uint32_t tiles_x_magic,
-                     const TileDesc *__restrict__ tiles, orbfe_keypoint *__restrict__ records, orbfe_soa soa)
+                     const TileDesc *__restrict__ tiles, orbfe_keypoint *__restrict__ records, orbfe_soa soa, SteerArgs steer)
 {
     using G = TileGeom<R>;
     constexpr int P = G::kPitch;
@@ -1311,7 +1313,17 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
     __shared__ uint32_t s_kxy[64], s_kc0[64], s_kslot[64];
     __shared__ int s_mom[128];                               // their moments: m10, m01
     __shared__ float s_ang[64], s_cos[64], s_sin[64];        // angle and steering (cos, sin)
+    __shared__ int s_kiv[64];                                // interval of the orientation in the steering table (TAB)
+    __shared__ float s_breaks[R == 15 ? kSteerMaxBreaks : 1]; // the table's break points: the bisection of the angle lanes reads LDS
+                                                              // (from global memory its 10 dependent loads were 15 % of the kernel)
     __shared__ int s_nkp, s_cursor;
+    // TAB: the rotated pattern comes from the orientation table (steer_table.cpp) instead of being computed: in the
+    // degrees-as-radians regime (R = 15 <=> !angle_in_radians) the 512 rotated sample positions are a piecewise
+    // constant function of the orientation with ~220 pieces, so a keypoint's 8 samples per lane are one 16-byte load
+    // (none at all in the piece around 0, which holds 70 % of the orientations: its row stays in registers) + 8 adds
+    // instead of 80 float instructions.  The table is generated with this very arithmetic and checked against it for
+    // every float in [-pi, pi] (orbfe_selfcheck_steer_table).
+    constexpr bool TAB = R == 15; // (R = 15 is launched only with !angle_in_radians, and then the context holds the table)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1348,6 +1360,8 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
                                              (__attribute__((address_space(3))) void *)(s_tile + 16 * (256 * t + 64 * wv)), 16, 0, 0);
         }
     }
+    if (TAB)
+        for (int i = tid; i < steer.n_breaks; i += 256) s_breaks[i] = steer.breaks[i];
     // cells of this tile: edge cl = cell >> l pixels of the level, n per tile edge (1 .. 64), in groups of 64
     const int cl = g.cell >> l;
     const int n = kDTile / cl, ln = ilog2(n);
@@ -1355,6 +1369,7 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
     // weight fragments of the moment MFMAs and this lane's four rBRIEF pattern rows (loaded in the first pass)
     uint4 bw[G::kMom];
     float4 pat[4];
+    uint4 central_off = make_uint4(0u, 0u, 0u, 0u);
     int cursor = 0; // next cell group (uniform)
     bool first = true;
     for (;;) {
@@ -1441,7 +1456,9 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
 #pragma unroll
             for (int ks = 0; ks < G::kMom; ks++) bw[ks] = momw[ks * 64 + lane];
 #pragma unroll
-            for (int r = 0; r < 4; r++) pat[r] = reinterpret_cast<const float4 *>(c_pattern_f)[64 * r + lane];
+            for (int r = 0; r < 4; r++)
+                if (!TAB) pat[r] = reinterpret_cast<const float4 *>(c_pattern_f)[64 * r + lane];
+            if (TAB) central_off = steer.table[steer.central * 64 + lane];
             first = false;
         }
 
@@ -1503,6 +1520,15 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
             s_ang[lane] = ang;
             s_cos[lane] = ca;
             s_sin[lane] = sb;
+            if (TAB) { // interval = number of break points <= the orientation: branch-free bisection
+                int pos = 0;
+#pragma unroll
+                for (int step = 512; step > 0; step >>= 1) {
+                    const int t = pos + step;
+                    if (t <= steer.n_breaks && s_breaks[t - 1] <= ang) pos = t;
+                }
+                s_kiv[lane] = pos;
+            }
             *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(records + (size_t)f * g.cap) + s_kslot[lane] + 16) = __float_as_uint(ang);
         }
         __syncthreads();
@@ -1524,8 +1550,13 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
         // waits for them inside the loop, four s_waitcnt per keypoint.
         const uint32_t my_c0 = s_kc0[lane], my_roff = s_kslot[lane];
         const uint32_t my_cos = __float_as_uint(s_cos[lane]), my_sin = __float_as_uint(s_sin[lane]);
+        const int my_iv = TAB ? s_kiv[lane] : 0;
+        if (!TAB) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) asm volatile("" ::"v"(pat[r].x), "v"(pat[r].y), "v"(pat[r].z), "v"(pat[r].w));
+            for (int r = 0; r < 4; r++) asm volatile("" ::"v"(pat[r].x), "v"(pat[r].y), "v"(pat[r].z), "v"(pat[r].w));
+        } else {
+            asm volatile("" ::"v"(central_off.x), "v"(central_off.y), "v"(central_off.z), "v"(central_off.w));
+        }
         for (int j = wv; j < nkp; j += 4) { // uniform
             const uint32_t c0f = (uint32_t)__builtin_amdgcn_readlane((int)my_c0, j);
             const uint32_t roff = (uint32_t)__builtin_amdgcn_readlane((int)my_roff, j);
@@ -1533,7 +1564,29 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
             const float b = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)my_sin, j));
             const char *rec = frame_rec + roff;
             uint64_t d[4] = {0, 0, 0, 0};
-            if (!(c0f >> 31)) orb_describe_lds<P>(s_tile, (int)c0f, a, b, pat, d);
+            if (!(c0f >> 31)) {
+                if (TAB) {
+                    const int iv = __builtin_amdgcn_readlane(my_iv, j);
+                    uint4 off = central_off;
+                    if (iv != steer.central) off = steer.table[iv * 64 + lane]; // uniform branch
+                    const uint32_t w[4] = {off.x, off.y, off.z, off.w};
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { // (P, Q) of round r as two signed 16-bit LDS offsets
+                        const int t0 = s_tile[(int)c0f + (int)(int16_t)(w[r] & 0xFFFFu)];
+                        const int t1 = s_tile[(int)c0f + ((int)w[r] >> 16)];
+                        d[r] = __ballot(t0 < t1);
+                    }
+                    // round r holds bit t of word p_t[r] (the bank-aware schedule of steer_table.cpp): four masked
+                    // swaps of whole ballots put the words back -- wave-uniform operands, scalar unit only
+                    uint64_t t;
+                    t = (d[1] ^ d[3]) & steer.sched_mask[3]; d[1] ^= t; d[3] ^= t;
+                    t = (d[0] ^ d[2]) & steer.sched_mask[2]; d[0] ^= t; d[2] ^= t;
+                    t = (d[2] ^ d[3]) & steer.sched_mask[1]; d[2] ^= t; d[3] ^= t;
+                    t = (d[0] ^ d[1]) & steer.sched_mask[0]; d[0] ^= t; d[1] ^= t;
+                } else {
+                    orb_describe_lds<P>(s_tile, (int)c0f, a, b, pat, d);
+                }
+            }
             const u32x4 lo = {(uint32_t)d[0], (uint32_t)(d[0] >> 32), (uint32_t)d[1], (uint32_t)(d[1] >> 32)};
             const u32x4 hi = {(uint32_t)d[2], (uint32_t)(d[2] >> 32), (uint32_t)d[3], (uint32_t)(d[3] >> 32)};
 #ifdef ORBFE_DESC_VECTOR_STORE // (A/B build: the stores as vector instructions of lane 0)
@@ -2170,6 +2223,48 @@ match_window_ref_kernel(const orbfe_keypoint *__restrict__ records, const int32_
 // ======================================================================================
 using namespace orbfe;
 
+// Exhaustive check of the orientation table against the arithmetic it replaces: one thread per float `angle` in
+// [first, first + count) of the ORDERED bit patterns (positive floats ascending), both signs, all 512 rotated points.
+// round in which lane `lane` evaluates descriptor word `word` under the schedule masks (inverse of sched_perm)
+__device__ inline int sched_round(const SteerArgs &st, int lane, int word)
+{
+    int p[4] = {0, 1, 2, 3}, t;
+    if (st.sched_mask[0] >> lane & 1) { t = p[0]; p[0] = p[1]; p[1] = t; }
+    if (st.sched_mask[1] >> lane & 1) { t = p[2]; p[2] = p[3]; p[3] = t; }
+    if (st.sched_mask[2] >> lane & 1) { t = p[0]; p[0] = p[2]; p[2] = t; }
+    if (st.sched_mask[3] >> lane & 1) { t = p[1]; p[1] = p[3]; p[3] = t; }
+    return p[0] == word ? 0 : (p[1] == word ? 1 : (p[2] == word ? 2 : 3));
+}
+__global__ void __launch_bounds__(256) steer_check_kernel(SteerArgs st, int pitch, uint32_t first, uint32_t count,
+                                                          unsigned long long *bad)
+{
+    ORBFE_NO_CONTRACT
+    const int16_t *tab = reinterpret_cast<const int16_t *>(st.table);
+    unsigned long long mine = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < 2ull * count; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t bits = first + (uint32_t)(i >> 1) | ((uint32_t)(i & 1) << 31);
+        const float angle = __uint_as_float(bits);
+        int pos = 0;
+#pragma unroll
+        for (int step = 512; step > 0; step >>= 1) {
+            const int t = pos + step;
+            if (t <= st.n_breaks && st.breaks[t - 1] <= angle) pos = t;
+        }
+        float a, b;
+        orb_steer(angle, 0, &a, &b);
+        const int16_t *row_tab = tab + (size_t)pos * 512;
+        for (int t = 0; t < ORBFE_PATTERN_TESTS; t++)
+#pragma unroll
+            for (int which = 0; which < 2; which++) {
+                const float px = (float)c_pattern[4 * t + 2 * which], py = (float)c_pattern[4 * t + 2 * which + 1];
+                const float p1 = px * b, p2 = py * a, p3 = px * a, p4 = py * b;
+                const int off = (int)__builtin_rintf(p1 + p2) * pitch + (int)__builtin_rintf(p3 - p4);
+                mine += off != (int)row_tab[(t & 63) * 8 + 2 * sched_round(st, t & 63, t >> 6) + which];
+            }
+    }
+    if (mine) atomicAdd(bad, mine);
+}
+
 static inline hipStream_t S(orbfe_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 // grid and geometry of a launch over (items per frame) x (n frames) for kernels that place themselves with frame_item()
 // n / d for 0 <= n < 65536 and 1 <= d <= 256 as one s_mul_hi_u32 (device_common.hpp div_by_magic): magic = ceil(2^32 / d),
@@ -2344,6 +2439,17 @@ int orbfe_create(const orbfe_config *cfg, orbfe_ctx **out)
         const std::vector<int8_t> wt = make_tile_moment_weights();
         if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_momw_tile, wt.size());
         if (e == hipSuccess) e = hipMemcpy(ctx->d_momw_tile, wt.data(), wt.size(), hipMemcpyHostToDevice);
+        if (!g.angle_in_radians) { // the rotated pattern as a table: ~230 KB
+            std::vector<float> br;
+            std::vector<int16_t> off;
+            build_steer_table(TileGeom<15>::kPitch, &br, &off, &ctx->steer_central, ctx->steer_sched_mask);
+            ctx->n_steer_breaks = (int)br.size();
+            if (ctx->n_steer_breaks > kSteerMaxBreaks) e = hipErrorInvalidValue; // (222 today; the kernel's LDS copy holds 1024)
+            if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_steer_breaks, (br.size() + 1) * sizeof(float));
+            if (e == hipSuccess) e = hipMemcpy(ctx->d_steer_breaks, br.data(), br.size() * sizeof(float), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_steer_table, off.size() * sizeof(int16_t));
+            if (e == hipSuccess) e = hipMemcpy(ctx->d_steer_table, off.data(), off.size() * sizeof(int16_t), hipMemcpyHostToDevice);
+        }
     }
     {
         // Few keypoints per 64x64 tile (the reference regime: one per 32-px cell = 4 per tile): staging a private
@@ -2382,6 +2488,8 @@ void orbfe_destroy(orbfe_ctx *ctx)
     if (ctx->d_selcount) (void)hipFree(ctx->d_selcount);
     if (ctx->d_cellslot) (void)hipFree(ctx->d_cellslot);
     if (ctx->d_momw_tile) (void)hipFree(ctx->d_momw_tile);
+    if (ctx->d_steer_breaks) (void)hipFree(ctx->d_steer_breaks);
+    if (ctx->d_steer_table) (void)hipFree(ctx->d_steer_table);
     if (ctx->d_tiles) (void)hipFree(ctx->d_tiles);
     if (ctx->d_mdesc) (void)hipFree(ctx->d_mdesc);
     if (ctx->d_mpos) (void)hipFree(ctx->d_mpos);
@@ -2572,17 +2680,19 @@ int orbfe_describe_batch(orbfe_ctx *ctx, int n_frames, orbfe_keypoint *d_records
         else ORBFE_DESCRIBE_LAUNCH2(KERNEL, false, GRID, __VA_ARGS__);                                              \
     } while (0)
     const DeviceGeom gl = with_frames(g, n_frames);
+    const SteerArgs steer{ctx->d_steer_breaks, ctx->d_steer_table, ctx->n_steer_breaks, ctx->steer_central,
+                          {ctx->steer_sched_mask[0], ctx->steer_sched_mask[1], ctx->steer_sched_mask[2], ctx->steer_sched_mask[3]}};
     if (patch) {
         ORBFE_DESCRIBE_LAUNCH(describe_kernel, frame_grid((g.cap + 4 * kKpw - 1) / (4 * kKpw), n_frames), gl, ctx->d_pyr, ctx->d_sel,
                               ctx->d_selcount, ctx->d_momw, d_records, so);
     } else if (g.descriptor_level) { // one workgroup per detection tile: (level, 64x64 tile of that level)
         if (ctx->n_tiles > 0)
             ORBFE_DESCRIBE_LAUNCH2(describe_tile_kernel, true, frame_grid(ctx->n_tiles, n_frames), gl, ctx->d_pyr, ctx->d_cellkey,
-                                   ctx->d_cellslot, ctx->d_momw_tile, 0, 0u, ctx->d_tiles, d_records, so);
+                                   ctx->d_cellslot, ctx->d_momw_tile, 0, 0u, ctx->d_tiles, d_records, so, steer);
     } else {
         const int tiles_x = (g.W + kDTile - 1) / kDTile, tiles_y = (g.H + kDTile - 1) / kDTile;
         ORBFE_DESCRIBE_LAUNCH2(describe_tile_kernel, false, frame_grid(tiles_x * tiles_y, n_frames), gl, ctx->d_pyr, ctx->d_cellkey,
-                               ctx->d_cellslot, ctx->d_momw_tile, tiles_x, magic_of(tiles_x), (const TileDesc *)nullptr, d_records, so);
+                               ctx->d_cellslot, ctx->d_momw_tile, tiles_x, magic_of(tiles_x), (const TileDesc *)nullptr, d_records, so, steer);
     }
 #undef ORBFE_DESCRIBE_LAUNCH2
 #undef ORBFE_DESCRIBE_LAUNCH
@@ -2695,6 +2805,31 @@ int orbfe_dispatch_info(const orbfe_ctx *ctx, int n_frames, int mode, int window
              match_path(ctx, n_frames, mode, window) == kMatchMfma || match_path(ctx, n_frames, mode, window) == kMatchValu256 ||
                      match_path(ctx, n_frames, mode, window) == kMatchRefLiteral
                  ? "all_pairs" : "window_cells");
+    return ORBFE_OK;
+}
+
+int orbfe_selfcheck_steer_table(orbfe_ctx *ctx, unsigned long long *n_angles, unsigned long long *n_mismatch)
+{
+    if (!ctx || !n_angles || !n_mismatch) return ORBFE_ERR_INVALID_ARG;
+    *n_angles = *n_mismatch = 0;
+    if (!ctx->d_steer_table) return ORBFE_OK; // angle_in_radians: the offsets are computed, there is no table
+    DeviceScope dev(ctx->cfg.device);
+    if (!dev.ok) CTX_FAIL(ctx, ORBFE_ERR_HIP, "selfcheck_steer_table: hipSetDevice(%d) failed", ctx->cfg.device);
+    unsigned long long *d_bad = nullptr;
+    ORBFE_HIP_TRY(ctx->err, hipMalloc((void **)&d_bad, sizeof(*d_bad)));
+    ORBFE_HIP_TRY(ctx->err, hipMemset(d_bad, 0, sizeof(*d_bad)));
+    uint32_t pi_bits;
+    const float pi = ORBFE_PI_F; // atan2f's range: [-pi, pi] as floats
+    memcpy(&pi_bits, &pi, 4);
+    const uint32_t count = pi_bits + 1; // bit patterns 0 .. pi_bits, each with both signs
+    const SteerArgs st{ctx->d_steer_breaks, ctx->d_steer_table, ctx->n_steer_breaks, ctx->steer_central,
+                       {ctx->steer_sched_mask[0], ctx->steer_sched_mask[1], ctx->steer_sched_mask[2], ctx->steer_sched_mask[3]}};
+    hipLaunchKernelGGL(steer_check_kernel, dim3(256 * 32), dim3(256), 0, 0, st, (int)TileGeom<15>::kPitch, 0u, count, d_bad);
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(n_mismatch, d_bad, sizeof(*d_bad), hipMemcpyDeviceToHost);
+    (void)hipFree(d_bad);
+    if (e != hipSuccess) CTX_FAIL(ctx, ORBFE_ERR_HIP, "selfcheck_steer_table: %s", hipGetErrorString(e));
+    *n_angles = 2ull * count;
     return ORBFE_OK;
 }
 

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "../../include/orbfe.h"
 #include "../../include/orbfe_math.h"
@@ -150,6 +151,18 @@ struct DeviceGeom { // passed by value to kernels
     LevelInfo lv[kMaxLevels];
 };
 
+// steer_table.cpp: orientation -> rotated rBRIEF sample offsets for LDS tiles of row pitch `pitch`; *offsets =
+// [intervals = breaks + 1][lane 64][8] int16 (P, Q of rounds 0..3), interval of an orientation = number of break
+// points <= it, *central = the interval of orientation 0
+void build_steer_table(int pitch, std::vector<float> *breaks, std::vector<int16_t> *offsets, int *central, uint64_t sched_mask[4]);
+// what the tile describe kernel needs of it (null table: compute the offsets instead)
+struct SteerArgs {
+    const float *breaks;
+    const uint4 *table;
+    int n_breaks, central;
+    uint64_t sched_mask[4]; // lanes whose schedule bit 0..3 is set (steer_table.cpp)
+};
+
 // match_mfma.hip: 256-bit brute-force matching on the matrix cores; pair k = frames
 // (first + k * stride, first + k * stride + 1), results at k * cap
 constexpr int kMmaMaxKeypoints = 16384;
@@ -200,6 +213,12 @@ struct orbfe_ctx {
     int32_t *d_selcount = nullptr;  // [max_batch]
     uint16_t *d_cellslot = nullptr; // [max_batch][K] record slot of each cell's keypoint, 0xFFFF = not selected
     uint4 *d_momw_tile = nullptr;   // describe (tile form): int8 weight fragments of the moment MFMAs
+    // describe (tile form, degrees-as-radians regime): the rotated pattern as a table over the orientation
+    // (steer_table.cpp): break points, per interval and lane the 8 sample offsets, the interval that holds 0
+    float *d_steer_breaks = nullptr;
+    uint4 *d_steer_table = nullptr;
+    int n_steer_breaks = 0, steer_central = 0;
+    uint64_t steer_sched_mask[4] = {0, 0, 0, 0};
     int describe_patch = 0;         // 1: sparse regime, patch kernel for large calls; 2 / -1: forced by ORBFE_DESCRIBE=patch / tile
     uint8_t *d_mdesc = nullptr;     // [max_batch][cap][32]  matcher scratch: dense descriptors
     uint8_t *d_mpos = nullptr;      // [max_batch][cap] float2 matcher scratch: positions

@@ -118,6 +118,7 @@ _SIGS = {
     "orbfe_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "orbfe_stream_sync": (C.c_int, [C.c_void_p]),
     "orbfe_dispatch_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+    "orbfe_selfcheck_steer_table": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
 }
 
 EXPORTS = tuple(_SIGS)  # every symbol include/orbfe.h declares
@@ -293,6 +294,12 @@ class Context:
         buf = C.create_string_buffer(512)
         check(lib().orbfe_dispatch_info(self.handle, n_frames, mode, window, buf, 512), self.handle)
         return dict(kv.split("=", 1) for kv in buf.value.decode().split(";"))
+
+    def selfcheck_steer_table(self):
+        """(orientations checked, mismatching sample offsets): the steering table against the arithmetic, exhaustively."""
+        n, bad = C.c_ulonglong(0), C.c_ulonglong(0)
+        check(lib().orbfe_selfcheck_steer_table(self.handle, C.byref(n), C.byref(bad)), self.handle)
+        return n.value, bad.value
 
     def read_level(self, level, frame=0, stream=0):
         """Copy one pyramid level of one frame to a numpy array [h, w] (harness helper)."""

@@ -300,3 +300,17 @@ def test_stage_detect_prechecks_at_every_threshold_range(gpu, oracle_mod, thr):
     torch, orbfe = gpu
     n = _detect_case(torch, orbfe, oracle_mod, 424, 240, 3, 9, thr, True, 0)
     assert n > 0 or thr >= 127.0
+
+
+def test_steering_table_equals_the_arithmetic_for_every_orientation(gpu):
+    """The tile describe kernel looks the rotated rBRIEF sample offsets up by orientation (steer_table.cpp; generated
+    at build time with the oracle's float arithmetic).  Exhaustive proof on the device: every float in [-pi, pi],
+    all 512 pattern points, table == orb.cu:12-14 / :42-46 as evaluated everywhere else."""
+    torch, orbfe = gpu
+    ctx = orbfe.Context(640, 480, max_batch=1, levels=1)
+    n, bad = ctx.selfcheck_steer_table()
+    assert n == 2 * (0x40490FDB + 1) and bad == 0, (n, bad)
+    ctx.close()
+    rad = orbfe.Context(640, 480, max_batch=1, levels=1, cell=8, min_arc=9, angle_in_radians=1)
+    assert rad.selfcheck_steer_table() == (0, 0)  # no table in that regime: the offsets are computed
+    rad.close()
