@@ -1515,11 +1515,13 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
         // ---- phase B: one lane per keypoint: atan2f and the steering cos / sin, ONCE per pass
         if (wv == 0 && lane < nkp) {
             const float ang = orbfe_atan2f((float)s_mom[2 * lane + 1], (float)s_mom[2 * lane]);
-            float ca, sb;
-            orb_steer(ang, g.angle_in_radians, &ca, &sb);
             s_ang[lane] = ang;
-            s_cos[lane] = ca;
-            s_sin[lane] = sb;
+            if (!TAB) { // (with the table the steering cos / sin are never formed: ~60 instructions of this serial phase)
+                float ca, sb;
+                orb_steer(ang, g.angle_in_radians, &ca, &sb);
+                s_cos[lane] = ca;
+                s_sin[lane] = sb;
+            }
             if (TAB) { // interval = number of break points <= the orientation: branch-free bisection
                 int pos = 0;
 #pragma unroll
@@ -1549,7 +1551,7 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
         // trip in the loop).  The empty asm makes the pattern rows' loads complete HERE: the compiler otherwise
         // waits for them inside the loop, four s_waitcnt per keypoint.
         const uint32_t my_c0 = s_kc0[lane], my_roff = s_kslot[lane];
-        const uint32_t my_cos = __float_as_uint(s_cos[lane]), my_sin = __float_as_uint(s_sin[lane]);
+        const uint32_t my_cos = TAB ? 0u : __float_as_uint(s_cos[lane]), my_sin = TAB ? 0u : __float_as_uint(s_sin[lane]);
         const int my_iv = TAB ? s_kiv[lane] : 0;
         if (!TAB) {
 #pragma unroll
