@@ -290,7 +290,7 @@ __device__ inline TileDesc load_tile_desc(const TileDesc *tiles, int i)
     return TileDesc{(int16_t)(raw & 0xFFFFu), (int16_t)((raw >> 16) & 0xFFFFu), (int16_t)((raw >> 32) & 0xFFFFu), 0};
 }
 
-constexpr int kSteerMaxBreaks = 1024; // LDS copy of the steering table's break points in the tile describe kernel
+constexpr int kSteerMaxBreaks = 256; // LDS copy of the steering table's break points in the tile describe kernel (222 today)
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 __device__ inline us2 U2(uint32_t v) { return __builtin_bit_cast(us2, v); }
@@ -1525,7 +1525,7 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
             if (TAB) { // interval = number of break points <= the orientation: branch-free bisection
                 int pos = 0;
 #pragma unroll
-                for (int step = 512; step > 0; step >>= 1) {
+                for (int step = kSteerMaxBreaks / 2; step > 0; step >>= 1) {
                     const int t = pos + step;
                     if (t <= steer.n_breaks && s_breaks[t - 1] <= ang) pos = t;
                 }
@@ -2446,7 +2446,7 @@ int orbfe_create(const orbfe_config *cfg, orbfe_ctx **out)
             std::vector<int16_t> off;
             build_steer_table(TileGeom<15>::kPitch, &br, &off, &ctx->steer_central, ctx->steer_sched_mask);
             ctx->n_steer_breaks = (int)br.size();
-            if (ctx->n_steer_breaks > kSteerMaxBreaks) e = hipErrorInvalidValue; // (222 today; the kernel's LDS copy holds 1024)
+            if (ctx->n_steer_breaks > kSteerMaxBreaks) e = hipErrorInvalidValue; // (222 today; the kernel's LDS copy holds 256)
             if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_steer_breaks, (br.size() + 1) * sizeof(float));
             if (e == hipSuccess) e = hipMemcpy(ctx->d_steer_breaks, br.data(), br.size() * sizeof(float), hipMemcpyHostToDevice);
             if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_steer_table, off.size() * sizeof(int16_t));
