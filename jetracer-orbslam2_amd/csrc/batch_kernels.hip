@@ -1034,9 +1034,11 @@ template <int R, bool SOA, bool DL>
 __global__ void __launch_bounds__(256)
 describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__restrict__ sel,
                 const int32_t *__restrict__ selcount, const uint4 *__restrict__ momw,
-                orbfe_keypoint *__restrict__ records, orbfe_soa soa)
+                orbfe_keypoint *__restrict__ records, orbfe_soa soa, SteerArgs steer)
 {
     using G = PatchGeom<R>;
+    // TAB: sample offsets from the orientation table (as in describe_tile_kernel; R = 15 <=> !angle_in_radians)
+    constexpr bool TAB = R == 15;
     constexpr int kRows = G::kRows, kPitch = G::kPitch, kPatchBytes = G::kPatchBytes;
     // + 256 bytes: the last moment step of the last patch reads (zero-weighted) bytes past it
     __shared__ __attribute__((aligned(16))) uint8_t s_patch[4 * kKpw * kPatchBytes + 256];
@@ -1059,8 +1061,15 @@ describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__re
 #pragma unroll
     for (int ks = 0; ks < G::kMom; ks++) bw[ks] = momw[ks * 64 + lane];
     float4 pat[4];
+    // TAB: lane i holds break points i, i + 64, i + 128, i + 192 of the table (+inf past the end): a keypoint's
+    // interval = the number of break points <= its orientation = four ballots + four s_bcnt1, no search
+    float brk[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) pat[r] = reinterpret_cast<const float4 *>(c_pattern_f)[64 * r + lane];
+    for (int r = 0; r < 4; r++) {
+        if (!TAB) pat[r] = reinterpret_cast<const float4 *>(c_pattern_f)[64 * r + lane];
+        else brk[r] = 64 * r + lane < steer.n_breaks ? steer.breaks[64 * r + lane] : __builtin_inff();
+    }
+    static_assert(kSteerMaxBreaks <= 256, "four break points per lane");
 
     int kx[kKpw], ky[kKpw], kax[kKpw], m10[kKpw], m01[kKpw], klv[kKpw];
     uint32_t kcell[kKpw], kkey[kKpw];
@@ -1192,8 +1201,20 @@ describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__re
         lm01 = lane == it ? m01[it] : lm01;
     }
     const float langle = orbfe_atan2f((float)lm01, (float)lm10);
-    float la, lb;
-    orb_steer(langle, g.angle_in_radians, &la, &lb);
+    float la = 0.f, lb = 0.f;
+    if (!TAB) orb_steer(langle, g.angle_in_radians, &la, &lb);
+    // TAB: the four keypoints' table rows, requested together before the first is used
+    uint4 rows[kKpw];
+    if (TAB) {
+#pragma unroll
+        for (int it = 0; it < kKpw; it++) {
+            const float ang = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(langle), it));
+            int iv = 0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) iv += (int)__popcll(__ballot(brk[r] <= ang));
+            rows[it] = steer.table[iv * 64 + lane];
+        }
+    }
     // ---- pass 3: descriptors + records
 #pragma unroll
     for (int it = 0; it < kKpw; it++) {
@@ -1204,8 +1225,25 @@ describe_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint4 *__re
         const int x = kx[it], y = ky[it], l = klv[it];
         // samples are addressed relative to s_patch: the keypoint's byte offset in it is one constant
         uint64_t d[4] = {0, 0, 0, 0};
-        if (!orb_border_zero(x, y, g.lv[l].w, g.lv[l].h, g.angle_in_radians))
-            orb_describe_lds<G::kPitch>(s_patch, (wv * kKpw + it) * kPatchBytes + R * G::kPitch + x - kax[it], a, b, pat, d);
+        if (!orb_border_zero(x, y, g.lv[l].w, g.lv[l].h, g.angle_in_radians)) {
+            const int c0 = (wv * kKpw + it) * kPatchBytes + R * G::kPitch + x - kax[it];
+            if (TAB) {
+                const uint32_t w[4] = {rows[it].x, rows[it].y, rows[it].z, rows[it].w};
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int t0 = s_patch[c0 + (int)(int16_t)(w[r] & 0xFFFFu)];
+                    const int t1 = s_patch[c0 + ((int)w[r] >> 16)];
+                    d[r] = __ballot(t0 < t1);
+                }
+                uint64_t t; // undo the round schedule (steer_table.cpp), scalar unit
+                t = (d[1] ^ d[3]) & steer.sched_mask[3]; d[1] ^= t; d[3] ^= t;
+                t = (d[0] ^ d[2]) & steer.sched_mask[2]; d[0] ^= t; d[2] ^= t;
+                t = (d[2] ^ d[3]) & steer.sched_mask[1]; d[2] ^= t; d[3] ^= t;
+                t = (d[0] ^ d[1]) & steer.sched_mask[0]; d[0] ^= t; d[1] ^= t;
+            } else {
+                orb_describe_lds<G::kPitch>(s_patch, c0, a, b, pat, d);
+            }
+        }
 
         // every value is wave-uniform: lane 0 stores the 13 dwords of the record
         if (lane == 0) {
@@ -2451,6 +2489,9 @@ int orbfe_create(const orbfe_config *cfg, orbfe_ctx **out)
             if (e == hipSuccess) e = hipMemcpy(ctx->d_steer_breaks, br.data(), br.size() * sizeof(float), hipMemcpyHostToDevice);
             if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_steer_table, off.size() * sizeof(int16_t));
             if (e == hipSuccess) e = hipMemcpy(ctx->d_steer_table, off.data(), off.size() * sizeof(int16_t), hipMemcpyHostToDevice);
+            build_steer_table(PatchGeom<15>::kPitch, &br, &off, &ctx->steer_central, ctx->steer_sched_mask);
+            if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_steer_table_patch, off.size() * sizeof(int16_t));
+            if (e == hipSuccess) e = hipMemcpy(ctx->d_steer_table_patch, off.data(), off.size() * sizeof(int16_t), hipMemcpyHostToDevice);
         }
     }
     {
@@ -2492,6 +2533,7 @@ void orbfe_destroy(orbfe_ctx *ctx)
     if (ctx->d_momw_tile) (void)hipFree(ctx->d_momw_tile);
     if (ctx->d_steer_breaks) (void)hipFree(ctx->d_steer_breaks);
     if (ctx->d_steer_table) (void)hipFree(ctx->d_steer_table);
+    if (ctx->d_steer_table_patch) (void)hipFree(ctx->d_steer_table_patch);
     if (ctx->d_tiles) (void)hipFree(ctx->d_tiles);
     if (ctx->d_mdesc) (void)hipFree(ctx->d_mdesc);
     if (ctx->d_mpos) (void)hipFree(ctx->d_mpos);
@@ -2684,9 +2726,11 @@ int orbfe_describe_batch(orbfe_ctx *ctx, int n_frames, orbfe_keypoint *d_records
     const DeviceGeom gl = with_frames(g, n_frames);
     const SteerArgs steer{ctx->d_steer_breaks, ctx->d_steer_table, ctx->n_steer_breaks, ctx->steer_central,
                           {ctx->steer_sched_mask[0], ctx->steer_sched_mask[1], ctx->steer_sched_mask[2], ctx->steer_sched_mask[3]}};
+    SteerArgs steerp = steer;
+    steerp.table = ctx->d_steer_table_patch;
     if (patch) {
         ORBFE_DESCRIBE_LAUNCH(describe_kernel, frame_grid((g.cap + 4 * kKpw - 1) / (4 * kKpw), n_frames), gl, ctx->d_pyr, ctx->d_sel,
-                              ctx->d_selcount, ctx->d_momw, d_records, so);
+                              ctx->d_selcount, ctx->d_momw, d_records, so, steerp);
     } else if (g.descriptor_level) { // one workgroup per detection tile: (level, 64x64 tile of that level)
         if (ctx->n_tiles > 0)
             ORBFE_DESCRIBE_LAUNCH2(describe_tile_kernel, true, frame_grid(ctx->n_tiles, n_frames), gl, ctx->d_pyr, ctx->d_cellkey,

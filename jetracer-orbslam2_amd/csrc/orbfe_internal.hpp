@@ -216,7 +216,8 @@ struct orbfe_ctx {
     // describe (tile form, degrees-as-radians regime): the rotated pattern as a table over the orientation
     // (steer_table.cpp): break points, per interval and lane the 8 sample offsets, the interval that holds 0
     float *d_steer_breaks = nullptr;
-    uint4 *d_steer_table = nullptr;
+    uint4 *d_steer_table = nullptr;       // offsets for the tile kernel's LDS pitch
+    uint4 *d_steer_table_patch = nullptr; // ... for the patch kernel's
     int n_steer_breaks = 0, steer_central = 0;
     uint64_t steer_sched_mask[4] = {0, 0, 0, 0};
     int describe_patch = 0;         // 1: sparse regime, patch kernel for large calls; 2 / -1: forced by ORBFE_DESCRIBE=patch / tile
