@@ -1388,6 +1388,9 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
     //      legal, and what lies outside the image is zeroed afterwards (border tiles only).
 #pragma unroll
     for (int t = 0; t < G::kTrips; t++) {
+#ifdef ORBFE_DESCRIBE_NOSTAGE // (timing experiment: no tile staging at all; results are wrong)
+        break;
+#endif
         const int q = 256 * t + tid;
         if (256 * (t + 1) <= G::kChunks || q < G::kChunks) {
             const int r = q / G::kChunksRow, cc = q - r * G::kChunksRow;
