@@ -2266,6 +2266,7 @@ match_window_ref_kernel(const orbfe_keypoint *__restrict__ records, const int32_
 // ======================================================================================
 using namespace orbfe;
 
+namespace orbfe {
 // Exhaustive check of the orientation table against the arithmetic it replaces: one thread per float `angle` in
 // [first, first + count) of the ORDERED bit patterns (positive floats ascending), both signs, all 512 rotated points.
 // round in which lane `lane` evaluates descriptor word `word` under the schedule masks (inverse of sched_perm)
@@ -2307,6 +2308,8 @@ __global__ void __launch_bounds__(256) steer_check_kernel(SteerArgs st, int pitc
     }
     if (mine) atomicAdd(bad, mine);
 }
+
+} // namespace orbfe
 
 static inline hipStream_t S(orbfe_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 // grid and geometry of a launch over (items per frame) x (n frames) for kernels that place themselves with frame_item()

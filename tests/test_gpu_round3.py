@@ -314,3 +314,18 @@ def test_steering_table_equals_the_arithmetic_for_every_orientation(gpu):
     rad = orbfe.Context(640, 480, max_batch=1, levels=1, cell=8, min_arc=9, angle_in_radians=1)
     assert rad.selfcheck_steer_table() == (0, 0)  # no table in that regime: the offsets are computed
     rad.close()
+
+
+@pytest.mark.parametrize("n", [7, 9, 16, 19])
+@pytest.mark.parametrize("which", ["patch", "tile"])
+def test_frame_counts_with_each_describe_kernel(gpu, oracle_mod, monkeypatch, which, n):
+    """Both describe kernels place their blocks with frame_item (rows of 8 frames) and both take the rotated pattern from
+    the orientation table in this regime: frame counts around a multiple of 8, reference regime and EXT regime."""
+    torch, orbfe = gpu
+    monkeypatch.setenv("ORBFE_DESCRIBE", which)
+    w, h = 320, 240
+    base = synth.frames(w, h, 5, 900 + n, "rects", **synth.DENSE)
+    frames = base[np.arange(n) % 5]
+    for cfg in (dict(levels=4), dict(levels=4, cell=16, min_arc=10, max_features=150)):
+        ctx, rec, cnt, soa = _run_extract(torch, orbfe, frames, **cfg)
+        assert _check_extract(oracle_mod, ctx, frames, rec, cnt, soa, **cfg) > 10 * n
