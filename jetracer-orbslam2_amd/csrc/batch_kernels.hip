@@ -644,7 +644,8 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
                 const uint32_t bit = (allflags >> (8 * i + 7 - trip)) & 1u;
                 const uint32_t e = trip < kMainTrips ? emain + (uint32_t)(trip << 7) + (uint32_t)i : ehalo + (uint32_t)i;
                 *reinterpret_cast<uint16_t *>(qb + dump + __umul24(bit, delta)) = (uint16_t)e;
-                delta += 2u * bit;
+                // delta += 2 * bit as ONE instruction (left to itself hipcc keeps a count and rebuilds delta from it: two)
+                asm("v_lshl_add_u32 %0, %1, 1, %0" : "+v"(delta) : "v"(bit));
             }
     }
     __syncthreads(); // the queue is complete
