@@ -377,28 +377,28 @@ __device__ inline int fast_score_packed(const uint8_t *p, uint32_t t2, int arc, 
     const uint32_t c = p[0];
     const us2 c2 = U2(c | (c << 16));
     const us2 hi = c2 + U2(t2), lo = ssub(c2, U2(t2));
-    const us2 one = U2(0x00010001u), two = U2(0x00020002u);
-    us2 sb = U2(0), sd = U2(0), mb = U2(0), md = U2(0);
+    const us2 one = U2(0x00010001u);
+    us2 sb = U2(0), sd = U2(0);
+    uint32_t bright = 0, dark = 0;
 #pragma unroll
-    for (int i = 7; i >= 0; i--) { // pair (ring i, ring i + 8); i descending so bit i = flag i
+    for (int i = 0; i < 8; i++) { // pair (ring i, ring i + 8)
         const uint32_t v0 = p[ring_dy(i) * kPxW + ring_dx(i)];
         const uint32_t v1 = p[ring_dy(i + 8) * kPxW + ring_dx(i + 8)];
         const us2 v = U2(v0 | (v1 << 16));
         const us2 ab = ssub(v, hi), ad = ssub(lo, v); // score terms v - (c+t), (c-t) - v, or 0
         sb = U2(U1(sb) + U1(ab)); // 8 terms <= 255 per 16-bit lane: no carry between the lanes, so a full-rate v_add_u32
         sd = U2(U1(sd) + U1(ad));
-        // mask = mask * 2 + (term != 0), as v_pk_min_u16 + v_pk_mad_u16.  Inline asm because hipcc
-        // rewrites min(x, 1) into per-half compare + select chains (3x the instructions).
-        uint32_t fb, fd, nb, nd;
+        // mask |= (term != 0) << ring position, both lanes at once: v_pk_min_u16 makes the flags 0 / 1, v_dot2_u32_u16
+        // adds flag.lo << i + flag.hi << (i + 8) to ONE 16-bit mask (rounds 1-2 shifted two 8-bit masks with v_pk_mad
+        // and merged them afterwards: 4 instructions more per candidate).  Inline asm because hipcc rewrites min(x, 1)
+        // into per-half compare + select chains (3x the instructions).
+        uint32_t fb, fd;
         asm("v_pk_min_u16 %0, %1, %2" : "=v"(fb) : "v"(U1(ab)), "v"(U1(one)));
         asm("v_pk_min_u16 %0, %1, %2" : "=v"(fd) : "v"(U1(ad)), "v"(U1(one)));
-        asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(nb) : "v"(U1(mb)), "v"(U1(two)), "v"(fb));
-        asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(nd) : "v"(U1(md)), "v"(U1(two)), "v"(fd));
-        mb = U2(nb);
-        md = U2(nd);
+        const uint32_t wgt = (1u << i) | (1u << (i + 24)); // lo lane: ring i, hi lane: ring i + 8
+        asm("v_dot2_u32_u16 %0, %1, %2, %0" : "+v"(bright) : "v"(fb), "s"(wgt));
+        asm("v_dot2_u32_u16 %0, %1, %2, %0" : "+v"(dark) : "v"(fd), "s"(wgt));
     }
-    const uint32_t ub = U1(mb), ud = U1(md);
-    const uint32_t bright = (ub & 0xFFu) | ((ub >> 16) << 8), dark = (ud & 0xFFu) | ((ud >> 16) << 8);
     if (arc == 0) {
         if (!(lut[bright] | lut[dark])) return 0;
     } else {
@@ -671,7 +671,7 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
             }
         }
         const uint64_t m = __ballot(pos);
-        if (pos) q1[q2slot(n2 + (int)__popcll(m & ((1ull << lane) - 1ull)))] = (uint16_t)e;
+        if (pos) q1[q2slot(n2 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)))] = (uint16_t)e;
         n2 += (int)__popcll(m);
     }
     __syncthreads(); // every wave's scores are in s_sc
