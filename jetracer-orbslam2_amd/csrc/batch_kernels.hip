@@ -490,12 +490,16 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
             // flight together (a conditional load is followed by its own s_waitcnt vmcnt(0): six memory
             // latencies in a row).  Lanes past the tile's last dword re-load their first one.
             uint32_t v[kLoadTrips];
+            // rows above the level's first one give a NEGATIVE offset (guard band / previous level): the base moves
+            // up by 4 rows + 4 bytes (scalar arithmetic) so that every lane offset is a non-negative 32-bit number --
+            // the SGPR-base form of the load, no sign extension and no 64-bit vector add per load
+            const uint8_t *img0 = img - (ptrdiff_t)(4 * P + 4);
+            off += (uint32_t)(4 * P + 4);
             const uint32_t off0 = off;
 #pragma unroll
             for (int t = 0; t < kLoadTrips; t++) {
                 const bool in = 256 * (t + 1) <= kPxH * kPxDw || 256 * t + tid < kPxH * kPxDw;
-                // (int): rows above the level's first one give a NEGATIVE offset (guard band / previous level)
-                v[t] = *reinterpret_cast<const uint32_t *>(img + (int)(in ? off : off0));
+                v[t] = *reinterpret_cast<const uint32_t *>(img0 + (in ? off : off0));
                 off += dstep;
                 q += 256 % kPxDw;
                 if (q >= kPxDw) { // carry into the next row
@@ -527,8 +531,11 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
             }
         }
         static_assert((kScH * kScPitch * 2) % 16 == 0, "score tile is zeroed with 16-byte stores");
-        for (int i = tid; i < kScH * kScPitch / 8; i += 256)
-            reinterpret_cast<uint4 *>(s_sc)[i] = make_uint4(0u, 0u, 0u, 0u);
+        constexpr int kScQuads = kScH * kScPitch / 8; // 561 stores: two full rounds and a short one, no loop
+        static_assert(kScQuads > 512 && kScQuads <= 768, "score tile zeroing is unrolled for 3 rounds");
+        reinterpret_cast<uint4 *>(s_sc)[tid] = make_uint4(0u, 0u, 0u, 0u);
+        reinterpret_cast<uint4 *>(s_sc)[tid + 256] = make_uint4(0u, 0u, 0u, 0u);
+        if (tid < kScQuads - 512) reinterpret_cast<uint4 *>(s_sc)[tid + 512] = make_uint4(0u, 0u, 0u, 0u);
     }
     const int c = g.cell >> l, lc = ilog2(c);
     const bool lds_cells = c >= 4;
