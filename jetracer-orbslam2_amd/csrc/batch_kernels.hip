@@ -132,7 +132,7 @@ pyramid_tail_kernel(DeviceGeom g, uint8_t *__restrict__ pyr, int first_level)
 template <bool RGB>
 __global__ void __launch_bounds__(256)
 pyramid_fused_kernel(DeviceGeom g, uint8_t *__restrict__ pyr, const uint8_t *__restrict__ src, int src_pitch,
-                     size_t src_fstride, int tiles_x, uint32_t tiles_x_magic, uint32_t *__restrict__ cellkey)
+                     size_t src_fstride, int tiles_x, uint32_t tiles_x_magic, int keys_per_tile, uint32_t *__restrict__ cellkey)
 {
     __shared__ uint8_t s_l2[32 * 32], s_l3[16 * 16], s_l4[8 * 8], s_l5[4 * 4], s_l6[2 * 2];
     int f, tile;
@@ -142,8 +142,7 @@ pyramid_fused_kernel(DeviceGeom g, uint8_t *__restrict__ pyr, const uint8_t *__r
     // by-product: the frame's cell keys are cleared for the detection that follows (saves the
     // memset launch of detect_batch); tile t clears the t-th slice
     {
-        const int n_tiles = (int)(g.grid8 ? gridDim.x >> 3 : gridDim.x); // tiles per frame (frame_grid)
-        const int per = (g.K + n_tiles - 1) / n_tiles;
+        const int per = keys_per_tile; // ceil(K / tiles per frame), from the host (a runtime division here was ~35 instructions)
         const int hi = (tile + 1) * per < g.K ? (tile + 1) * per : g.K;
         for (int i = tile * per + tid; i < hi; i += 256) cellkey[(size_t)f * g.K + i] = 0u;
     }
@@ -2599,10 +2598,12 @@ static int build_pyramid_impl(orbfe_ctx *ctx, const uint8_t *d_src, size_t pitch
         const int tiles_x = (g.W + 127) / 128, tiles_y = (g.H + 127) / 128;
         if (rgb)
             hipLaunchKernelGGL(pyramid_fused_kernel<true>, frame_grid(tiles_x * tiles_y, n_frames), dim3(256), 0, S(stream),
-                               with_frames(g, n_frames), ctx->d_pyr, d_src, (int)pitch, frame_stride, tiles_x, magic_of(tiles_x), ctx->d_cellkey);
+                               with_frames(g, n_frames), ctx->d_pyr, d_src, (int)pitch, frame_stride, tiles_x, magic_of(tiles_x),
+                               (g.K + tiles_x * tiles_y - 1) / (tiles_x * tiles_y), ctx->d_cellkey);
         else
             hipLaunchKernelGGL(pyramid_fused_kernel<false>, frame_grid(tiles_x * tiles_y, n_frames), dim3(256), 0, S(stream),
-                               with_frames(g, n_frames), ctx->d_pyr, d_src, (int)pitch, frame_stride, tiles_x, magic_of(tiles_x), ctx->d_cellkey);
+                               with_frames(g, n_frames), ctx->d_pyr, d_src, (int)pitch, frame_stride, tiles_x, magic_of(tiles_x),
+                               (g.K + tiles_x * tiles_y - 1) / (tiles_x * tiles_y), ctx->d_cellkey);
         next_level = 8;
         // the fused kernel cleared these frames' cell keys; valid for a detect_batch issued next on
         // this stream in the same capture mode
