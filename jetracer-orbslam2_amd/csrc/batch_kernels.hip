@@ -619,7 +619,9 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
         }
         const uint32_t *row = s_px32 + (r + 3) * kPxDw;
         const uint32_t C = row[q];
-        const uint32_t L = q > 0 ? row[q - 1] : 0u, Rr = q < kPxDw - 1 ? row[q + 1] : 0u;
+        // (q = 0 / 17: the neighbour dword is the adjacent row's -- a valid LDS word whose bytes only reach pixels the
+        // mask drops: px = 3 takes its W from C's byte 0, px = 68 its E from C's byte 3 -- so the reads need no test)
+        const uint32_t L = row[q - 1], Rr = row[q + 1];
         const uint32_t Nd = row[q - 3 * kPxDw], Sd = row[q + 3 * kPxDw];
         const uint32_t Wd = __builtin_amdgcn_alignbyte(C, L, 1);
         const uint32_t Ed = __builtin_amdgcn_alignbyte(Rr, C, 3);
