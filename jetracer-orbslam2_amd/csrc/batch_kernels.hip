@@ -259,14 +259,14 @@ pyramid_fused_kernel(DeviceGeom g, uint8_t *__restrict__ pyr, const uint8_t *__r
 // a5 + a6 fused  FAST score + 3x3 NMS + per-cell maximum for one 64x64 tile of one level of
 // one frame.  Most pixels are not corners, so the work is staged to keep the lanes busy:
 //   A  load the pixel tile (4-px halo: ring radius 3 + NMS radius 1) into LDS as dwords
-//   B  compass pre-test on 4 pixels per lane with packed-u16 min/max: a cyclic arc of >= 9
-//      ring pixels holds one pixel of each opposite pair (N,S) and (E,W), one of >= 12 holds
-//      3 of the 4 compass pixels.  Survivors are compacted into an LDS queue.  (Pure
-//      work-skipping, like the reference's opposite-pair prechecks, fast.cu:98-124: it rejects
-//      no corner.)
-//   C  full 16-pixel ring test on queued candidates only, two ring pixels per packed-u16
-//      op (saturating subtracts give the score terms and the label flags at once); scores
-//      go to a u16 LDS tile; positive scores inside the tile are queued again
+//   B  compass pre-test on the 4 pixels of a dword at once, bytes in place (compass4: byte-wise compares as
+//      v_sub + v_bitop3): a cyclic arc of >= 9 ring pixels holds one pixel of each opposite pair (N,S) and
+//      (E,W), one of >= 12 holds 3 of the 4 compass pixels.  Survivors are compacted, branch-free, into ONE LDS
+//      queue per workgroup.  (Pure work-skipping, like the reference's opposite-pair prechecks,
+//      fast.cu:98-124: it rejects no corner.)
+//   C  full 16-pixel ring test on queued candidates only, batches of 64 dealt round-robin to the waves, two ring
+//      pixels per packed-u16 op (saturating subtracts give the score terms and the label flags at once); scores
+//      go to a u16 LDS tile; positive scores inside the tile are queued again, in place
 //   D  strict 3x3 maximum test on the positives only; winners atomicMax their nms_key()
 //      into the cell (LDS for cells >= 4 px, global for smaller cells)
 // ------------------------------------------------------------------------------------
@@ -295,8 +295,6 @@ typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 __device__ inline us2 U2(uint32_t v) { return __builtin_bit_cast(us2, v); }
 __device__ inline uint32_t U1(us2 v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ inline us2 ssub(us2 a, us2 b) { return __builtin_elementwise_sub_sat(a, b); }
-__device__ inline us2 pmin(us2 a, us2 b) { return __builtin_elementwise_min(a, b); }
-__device__ inline us2 pmax(us2 a, us2 b) { return __builtin_elementwise_max(a, b); }
 
 constexpr int kPxW = kTileW + 8, kPxH = kTileH + 8; // 72 x 72 pixel tile
 constexpr int kPxDw = kPxW / 4;                      // 18 dwords per row
