@@ -170,3 +170,46 @@ def test_empty_frame_message(L):
     assert L.orbfe_wire_frame_encode(C.byref(m), buf, need, None) == 0
     d = {k: v for k, _, v in decode(bytes(buf))}
     assert d["keypoints_x"] == b"" and d["image"] == b"" and d["az"] == -90
+
+
+def test_frame_message_through_an_independent_bson_decoder(L):
+    """The viewer decodes the message with the npm `bson` package's BSON.deserialize and reads msg.width / height /
+    channels, msg.image.buffer, msg.keypoints_x.buffer, msg.keypoints_y.buffer, msg.ax / ay / az
+    (CarDriver/src/hooks/useWebsockets.js:30-71; package.json: bson ^4.2.2 -- not vendored, cannot be run here).
+    PyMongo's `bson` is the same specification implemented by the same vendor and IS in this image: the bytes of
+    orbfe_wire_frame_encode must decode with it into exactly those fields -- int32 scalars and generic binaries
+    (subtype 0x80, user-defined, as bson.h:18 has it: the viewer only touches `.buffer`), in the producer's order
+    (WebSocketCom.cpp:167-184)."""
+    bson = pytest.importorskip("bson")
+    if not hasattr(bson, "decode"):
+        pytest.skip("a `bson` module without decode(): not PyMongo's")
+    import orbfe
+    rng = np.random.default_rng(12)
+    for n, img_bytes in ((0, 0), (1, 7), (405, 848 * 480)):
+        kx = rng.integers(0, 848, max(n, 1)).astype(np.uint16)[:n]
+        ky = rng.integers(0, 480, max(n, 1)).astype(np.uint16)[:n]
+        img = rng.integers(0, 256, max(img_bytes, 1)).astype(np.uint8)[:img_bytes]
+        m = orbfe.FrameMessage((C.c_float * 3)(0.3, -1.1, 2.0), 848, 480, 1, kx.ctypes.data if n else None,
+                               ky.ctypes.data if n else None, n, img.ctypes.data if img_bytes else None, img_bytes)
+        need = L.orbfe_wire_frame_size(C.byref(m))
+        buf = (C.c_uint8 * need)()
+        assert L.orbfe_wire_frame_encode(C.byref(m), buf, need, None) == 0
+        msg = bson.decode(bytes(buf))  # strict: raises on a malformed document, a bad length or trailing bytes
+        assert list(msg) == ["ax", "ay", "az", "width", "height", "channels", "keypoints_x", "keypoints_y", "image"]
+        ang = (C.c_int32 * 3)()
+        L.orbfe_wire_angles(m.theta, ang)
+        assert (msg["ax"], msg["ay"], msg["az"]) == tuple(ang)
+        assert all(type(msg[k]) is int for k in ("ax", "ay", "az", "width", "height", "channels"))
+        assert (msg["width"], msg["height"], msg["channels"]) == (848, 480, 1)
+        # what the viewer wraps: new Uint8Array(msg.image.buffer), Uint8Array.from(msg.keypoints_x.buffer)
+        assert bytes(msg["keypoints_x"]) == kx.tobytes() and bytes(msg["keypoints_y"]) == ky.tobytes()
+        assert bytes(msg["image"]) == img.tobytes()
+        for k in ("keypoints_x", "keypoints_y", "image"):
+            assert msg[k].subtype == 0x80, "the user-defined binary subtype the reference writes (bson.h:18)"
+        # and the other way round: the library's reader on a document PyMongo wrote
+        theirs = bson.encode({"width": 848, "image": bson.Binary(img.tobytes(), 0), "height": 480})
+        raw = (C.c_uint8 * len(theirs)).from_buffer_copy(theirs)
+        val, nb = C.c_void_p(), C.c_size_t()
+        assert L.orbfe_bson_find(raw, len(theirs), b"image", C.byref(val), C.byref(nb)) == 0x05 and nb.value == img_bytes
+        assert C.string_at(val.value, nb.value) == img.tobytes()
+        assert L.orbfe_bson_find(raw, len(theirs), b"height", C.byref(val), C.byref(nb)) == 0x10
