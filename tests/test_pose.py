@@ -130,3 +130,21 @@ def test_imu_complementary_filter_bits(L, oracle_mod):
         got = np.array(list(s.theta), np.float32)
         assert got.view(np.uint32).tolist() == ref.theta.view(np.uint32).tolist(), "step %d" % k
     assert abs(float(s.theta[1]) - np.pi) < 0.5  # started at pi (SlamGpuPipeline.cpp:227), drifted by the gyro only
+
+
+@pytest.mark.parametrize("n,noise", [(4, 0.0), (50, 0.02), (1000, 0.3)])
+def test_best_fit_transform_against_scipy_kabsch(L, n, noise):
+    """A third, independent implementation: SciPy's Kabsch solver (Rotation.align_vectors) on the centred point sets.
+    The reference's best_fit_transform (buildStream.cpp:29-90) is that algorithm (SVD of the cross-covariance with the
+    reflection fix); the product's own 3x3 Jacobi SVD must land on the same rotation and translation."""
+    Rotation = pytest.importorskip("scipy.spatial.transform").Rotation
+    rng = np.random.default_rng(100 + n)
+    A = rng.normal(size=(n, 3)) * [300, 200, 1500]
+    R, t = _rot(rng), rng.normal(size=3) * 20
+    B = A @ R.T + t + rng.normal(size=(n, 3)) * noise
+    T = _fit(L, A, B)
+    ca, cb = A.mean(0), B.mean(0)
+    rot, _ = Rotation.align_vectors(B - cb, A - ca)  # the rotation that takes A - ca onto B - cb
+    Rs = rot.as_matrix()
+    assert np.abs(T[:3, :3] - Rs).max() < 1e-8
+    assert np.abs(T[:3, 3] - (cb - Rs @ ca)).max() < 1e-6
