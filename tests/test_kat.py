@@ -321,3 +321,107 @@ def test_deprojection_known_answers(oracle_mod):
     np.testing.assert_allclose(pts[0], [2000 * (40 - 32) / 50, 2000 * (10 - 24) / 40, 2000], rtol=1e-6)
     p, pts, d, n = oracle_mod.keypoint_pixel_to_point(depth, k, pos, score, desc, 1)
     assert n == 1 and pts[0][2] == 3000
+
+
+def test_blur_and_pyramid_against_scipy_and_numpy(oracle_mod):
+    """Independent restatements of C.1 / C.2 with library primitives: away from the reference's
+    32-column shuffle seams and its unwritten rows (Q1, Q2) the level-0 image is scipy.ndimage's 3x3 binomial
+    convolution rounded as floor(s / 16 + 0.5) (gaussian_blur_3x3.cu:15-53); every further level is the truncated mean of
+    2x2 blocks (pyramid.cu:6-29), odd trailing row / column dropped."""
+    ndimage = pytest.importorskip("scipy.ndimage")
+    rng = np.random.default_rng(3)
+    for w, h in ((640, 480), (848, 480), (100, 70)):
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        got = oracle_mod.gaussian_blur_3x3(img)
+        k = np.array([[1, 2, 1], [2, 4, 2], [1, 2, 1]], np.int64)
+        s = ndimage.convolve(img.astype(np.int64), k, mode="nearest")
+        want = np.floor(s / 16.0 + 0.5).astype(np.uint8)
+        x = np.arange(w)
+        cols = (x % 32 != 0) & (x % 32 != 31) & (x != w - 1)  # columns whose left and right taps are the true neighbours
+        np.testing.assert_array_equal(got[1:h - 2][:, cols], want[1:h - 2][:, cols])
+        assert not got[0].any() and not got[h - 2:].any()      # Q1: rows 0, H-2, H-1 stay 0
+        lvl = got
+        for _ in range(4):
+            nxt = oracle_mod.halfsample(lvl)
+            hh, ww = lvl.shape[0] // 2, lvl.shape[1] // 2
+            blocks = lvl[:2 * hh, :2 * ww].astype(np.int64).reshape(hh, 2, ww, 2).sum(axis=(1, 3)) >> 2
+            np.testing.assert_array_equal(nxt, blocks.astype(np.uint8))
+            lvl = nxt
+
+
+@pytest.mark.parametrize("arc", [9, 10, 12])
+def test_fast_response_against_a_definition_level_numpy_restatement(oracle_mod, arc):
+    """The oracle restates fast.cu statement by statement (bit masks, LUT, prechecks).  Here is FAST as its DEFINITION,
+    vectorised over the image, with nothing shared with that code: label the 16 ring pixels brighter / darker than the
+    centre by more than t, a corner iff some `arc` cyclically consecutive ring pixels carry the same label, score =
+    max(sum of (p - c - t) over ALL brighter, sum of (c - p - t) over ALL darker) (fast.cu:196-255)."""
+    offs = [(0, 3), (-1, 3), (-2, 2), (-3, 1), (-3, 0), (-3, -1), (-2, -2), (-1, -3), (0, -3),
+            (1, -3), (2, -2), (3, -1), (3, 0), (3, 1), (2, 2), (1, 3)]
+    t = 13
+    for kind, w, h, seed in (("rects", 160, 120, 1), ("uniform", 96, 64, 2), ("checker", 80, 48, 3)):
+        img = synth.frame(w, h, seed, kind)
+        I = img.astype(np.int32)
+        c = I[3:h - 3, 3:w - 3]
+        ring = np.stack([I[3 + dy:h - 3 + dy, 3 + dx:w - 3 + dx] for dx, dy in offs])  # [16, h-6, w-6]
+        br, dk = ring > c + t, ring < c - t
+
+        def has_run(lab):  # some `arc` cyclically consecutive positions all labelled
+            run = np.ones_like(lab)
+            for k in range(arc):
+                run &= np.roll(lab, -k, axis=0)
+            return run.any(axis=0)
+
+        corner = has_run(br) | has_run(dk)
+        sb = np.where(br, ring - c - t, 0).sum(axis=0)
+        sd = np.where(dk, c - ring - t, 0).sum(axis=0)
+        want = np.zeros((h, w), np.float32)
+        want[3:h - 3, 3:w - 3] = np.where(corner, np.maximum(sb, sd), 0)
+        got = oracle_mod.fast_response(img, oracle_mod.fast_lut(arc), float(t))
+        np.testing.assert_array_equal(got, want)
+        assert (want > 0).any() or kind == "checker"
+
+
+@pytest.mark.parametrize("radians", [0, 1])
+def test_orientation_and_rbrief_against_definition_level_numpy(oracle_mod, radians):
+    """C.6 / C.7 of SURVEY.md Appendix C written down directly in numpy (nothing shared with oracle/orbfe_oracle.c but
+    the two transcendental routines, which the build has to own: include/orbfe_math.h): intensity-centroid moments over
+    the radius-15 disc with the reference's per-sample bounds (orb.cu:77-134), angle = ATAN2F(m01, m10); descriptor bit
+    i = I(P_i rotated) < I(Q_i rotated) with single-precision products, ONE single-precision add / subtract and
+    round-half-even, no contraction (orb.cu:12-14, :42-75), zero inside the guard band."""
+    u = [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 7, 5, 0]
+    w, h = 96, 80
+    img = synth.frame(w, h, 5, "uniform")
+    I = img.astype(np.int64)
+    rng = np.random.default_rng(8)
+    pos = np.stack([rng.integers(3, w - 3, 300), rng.integers(3, h - 3, 300)], axis=1).astype(np.float32)
+    pos[:8] = [[3, 3], [w - 4, h - 4], [16, 40], [17, 40], [w - 17, 40], [w - 16, 40], [40, 17], [40, h - 17]]
+    ang = oracle_mod.compute_fast_angle(pos, None, img)
+    pat = oracle_mod.pattern().reshape(256, 4).astype(np.float32)
+    desc, _ = oracle_mod.calc_orb(ang, pos, img, angle_in_radians=radians)
+    guard = 19 if radians else 17
+    for k in range(len(pos)):
+        kx, ky = int(pos[k, 0]), int(pos[k, 1])
+        m10 = m01 = 0
+        for dy in range(-15, 16):
+            y = ky + dy
+            if dy != 0 and not (0 < y < h):  # rows above / below: ky - dy > 0, ky + dy < h; the centre row has no test
+                continue
+            for dx in range(-u[abs(dy)], u[abs(dy)] + 1):
+                x = kx + dx
+                if 0 < x < w:
+                    m10 += dx * I[y, x]
+                    m01 += dy * I[y, x]
+        want = oracle_mod.atan2f(np.float32(m01), np.float32(m10))
+        assert ang[k].tobytes() == np.float32(want).tobytes(), (k, kx, ky)
+        lx, ly = kx, ky
+        if lx < guard or lx > w - guard - (1 if radians else 0) or ly < guard or ly > h - guard - (1 if radians else 0):
+            assert not desc[k].any()
+            continue
+        theta = ang[k] if radians else np.float32(ang[k] * np.float32(np.float32(3.141592654) / np.float32(180.0)))
+        b, a = oracle_mod.sincosf(theta)
+        def sample(px, py):  # one float32 product per term, one float32 add, round half to even
+            col = np.rint(np.float32(np.float32(px * a) - np.float32(py * b))).astype(int)
+            row = np.rint(np.float32(np.float32(px * b) + np.float32(py * a))).astype(int)
+            return I[ly + row, lx + col]
+        bits = (sample(pat[:, 0], pat[:, 1]) < sample(pat[:, 2], pat[:, 3])).astype(np.uint8)
+        np.testing.assert_array_equal(desc[k], np.packbits(bits.reshape(32, 8), axis=1, bitorder="little")[:, 0], err_msg=str(k))
