@@ -9,7 +9,9 @@
  * helper_cuda.h, librealsense2, Eigen).  This file is therefore a statement-by-statement
  * CPU restatement of those kernels with the determinisation decisions of SURVEY.md
  * Appendix A, pinned by the known answers derivable from the source (Appendix B) in
- * tests/test_kat.py and by committed digests in tests/golden/.
+ * tests/test_kat.py, by definition-level numpy / scipy restatements of blur, pyramid, FAST,
+ * orientation and rBRIEF that share nothing with this file (same tests file), and by committed
+ * digests in tests/golden/.
  */
 #ifndef ORBFE_ORACLE_H
 #define ORBFE_ORACLE_H
