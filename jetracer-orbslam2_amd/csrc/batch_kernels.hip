@@ -1342,8 +1342,17 @@ static std::vector<int8_t> make_tile_moment_weights()
 // and the keypoints that level won inside it, sampled at position >> level.  A level-l tile spans
 // (64 / (cell >> l))^2 cells, up to 4096, so the keypoint list is gathered in passes of at most 64 (wave 0
 // appends whole 64-cell groups while they fit); with DL = false there is exactly one group and one pass.
+// threads of a tile-describe workgroup.  128 since late r3: the kernel waits for its tile's round trip to memory at the
+// head of every workgroup (4.3), and with two waves per tile a CU holds 11 tiles in flight (LDS-bound) instead of 8
+// (wave-slot-bound): 1.390 -> 1.326 ms per 4096 frames.  -DORBFE_DESCRIBE_THREADS=256 is the A/B build.
+#ifndef ORBFE_DESCRIBE_THREADS
+#define ORBFE_DESCRIBE_THREADS 128
+#endif
+constexpr int kDescThreads = ORBFE_DESCRIBE_THREADS;
+static_assert(kDescThreads == 128 || kDescThreads == 256, "whole waves; the moment sums are zeroed by threads 0..127");
+
 template <int R, bool SOA, bool DL>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kDescThreads)
 describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32_t *__restrict__ cellkey,
                      const uint16_t *__restrict__ cellslot, const uint4 *__restrict__ momw, int tiles_x, uint32_t tiles_x_magic,
                      const TileDesc *__restrict__ tiles, orbfe_keypoint *__restrict__ records, orbfe_soa soa, SteerArgs steer)
@@ -1394,22 +1403,22 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
     //      Addresses are clamped into the image (rows) and the padded pitch (columns): every load is
     //      legal, and what lies outside the image is zeroed afterwards (border tiles only).
 #pragma unroll
-    for (int t = 0; t < G::kTrips; t++) {
+    for (int t = 0; t < (G::kChunks + kDescThreads - 1) / kDescThreads; t++) {
 #ifdef ORBFE_DESCRIBE_NOSTAGE // (timing experiment: no tile staging at all; results are wrong)
         break;
 #endif
-        const int q = 256 * t + tid;
-        if (256 * (t + 1) <= G::kChunks || q < G::kChunks) {
+        const int q = kDescThreads * t + tid;
+        if (kDescThreads * (t + 1) <= G::kChunks || q < G::kChunks) {
             const int r = q / G::kChunksRow, cc = q - r * G::kChunksRow;
             int gy = oy + r, gx = ox + 16 * cc;
             gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
             gx = gx < 0 ? 0 : (gx > IP - 16 ? IP - 16 : gx);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(img + (uint32_t)(__mul24(gy, IP) + gx)),
-                                             (__attribute__((address_space(3))) void *)(s_tile + 16 * (256 * t + 64 * wv)), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(s_tile + 16 * (kDescThreads * t + 64 * wv)), 16, 0, 0);
         }
     }
     if (TAB)
-        for (int i = tid; i < steer.n_breaks; i += 256) s_breaks[i] = steer.breaks[i];
+        for (int i = tid; i < steer.n_breaks; i += kDescThreads) s_breaks[i] = steer.breaks[i];
     // cells of this tile: edge cl = cell >> l pixels of the level, n per tile edge (1 .. 64), in groups of 64
     const int cl = g.cell >> l;
     const int n = kDTile / cl, ln = ilog2(n);
@@ -1482,8 +1491,8 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
                 constexpr int PD = P / 4;
                 const int rtop = oy <= 0 ? 1 - oy : 0;                       // rows [0, rtop) lie at gy <= 0
                 const int rbot = H - oy < G::kRows ? H - oy : G::kRows;      // rows [rbot, kRows) at gy >= H
-                for (int i = tid; i < rtop * PD; i += 256) t32[i] = 0u;
-                for (int i = rbot * PD + tid; i < G::kRows * PD; i += 256) t32[i] = 0u;
+                for (int i = tid; i < rtop * PD; i += kDescThreads) t32[i] = 0u;
+                for (int i = rbot * PD + tid; i < G::kRows * PD; i += kDescThreads) t32[i] = 0u;
                 // column strips of the rows in between: `lanes` threads per row, one dword each per pass
                 auto strip = [&](int d0, int nd, int first_keep, int last_keep) { // dwords [d0, d0 + nd); bytes outside [first_keep, last_keep) go
                     const int sh = nd <= 8 ? 3 : 5, d = d0 + (tid & ((1 << sh) - 1));
@@ -1495,7 +1504,7 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
                         if (lo > 0) keep &= 0xFFFFFFFFu << (8 * lo);
                         if (hi < 4) keep &= (1u << (8 * hi)) - 1u;
                     }
-                    for (int r = rtop + (tid >> sh); r < rbot; r += 256 >> sh) t32[r * PD + d] &= keep;
+                    for (int r = rtop + (tid >> sh); r < rbot; r += kDescThreads >> sh) t32[r * PD + d] &= keep;
                 };
                 if (ox <= 0) strip(0, (1 - ox + 3) / 4, 1 - ox, P);          // gx <= 0  <=> byte < 1 - ox
                 if (ox + P > W) strip((W - ox) / 4, PD - (W - ox) / 4, 0, W - ox); // gx >= W <=> byte >= W - ox
@@ -1511,7 +1520,7 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
         }
 
         // ---- phase A: moments of groups of kKpw keypoints on the matrix cores -> s_m10 / s_m01
-        for (int grp = wv; grp * kKpw < nkp; grp += 4) { // uniform
+        for (int grp = wv; grp * kKpw < nkp; grp += kDescThreads / 64) { // uniform
             const int k0 = grp * kKpw;
             const int nk = nkp - k0 < kKpw ? nkp - k0 : kKpw;
             // A fragment of lane (chunk c, row = keypoint + 4 * slice) = 16 bytes of disc-box row
@@ -1607,7 +1616,7 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
         } else {
             asm volatile("" ::"v"(central_off.x), "v"(central_off.y), "v"(central_off.z), "v"(central_off.w));
         }
-        for (int j = wv; j < nkp; j += 4) { // uniform
+        for (int j = wv; j < nkp; j += kDescThreads / 64) { // uniform
             const uint32_t c0f = (uint32_t)__builtin_amdgcn_readlane((int)my_c0, j);
             const uint32_t roff = (uint32_t)__builtin_amdgcn_readlane((int)my_roff, j);
             const float a = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)my_cos, j));
@@ -2728,10 +2737,11 @@ int orbfe_describe_batch(orbfe_ctx *ctx, int n_frames, orbfe_keypoint *d_records
     const bool want_soa = so.d_pos || so.d_score || so.d_level || so.d_angle || so.d_desc || so.d_desc32;
 #define ORBFE_DESCRIBE_LAUNCH2(KERNEL, DLV, GRID, ...)                                                               \
     do {                                                                                                            \
-        if (g.angle_in_radians && want_soa) hipLaunchKernelGGL((KERNEL<19, true, DLV>), GRID, dim3(256), 0, S(stream), __VA_ARGS__);  \
-        else if (g.angle_in_radians) hipLaunchKernelGGL((KERNEL<19, false, DLV>), GRID, dim3(256), 0, S(stream), __VA_ARGS__);        \
-        else if (want_soa) hipLaunchKernelGGL((KERNEL<15, true, DLV>), GRID, dim3(256), 0, S(stream), __VA_ARGS__);                   \
-        else hipLaunchKernelGGL((KERNEL<15, false, DLV>), GRID, dim3(256), 0, S(stream), __VA_ARGS__);                                \
+        const dim3 thr(sizeof(#KERNEL) == sizeof("describe_tile_kernel") ? kDescThreads : 256);                    \
+        if (g.angle_in_radians && want_soa) hipLaunchKernelGGL((KERNEL<19, true, DLV>), GRID, thr, 0, S(stream), __VA_ARGS__);  \
+        else if (g.angle_in_radians) hipLaunchKernelGGL((KERNEL<19, false, DLV>), GRID, thr, 0, S(stream), __VA_ARGS__);        \
+        else if (want_soa) hipLaunchKernelGGL((KERNEL<15, true, DLV>), GRID, thr, 0, S(stream), __VA_ARGS__);                   \
+        else hipLaunchKernelGGL((KERNEL<15, false, DLV>), GRID, thr, 0, S(stream), __VA_ARGS__);                                \
     } while (0)
 #define ORBFE_DESCRIBE_LAUNCH(KERNEL, GRID, ...)                                                                    \
     do {                                                                                                            \
