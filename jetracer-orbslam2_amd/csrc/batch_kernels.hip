@@ -289,7 +289,7 @@ __device__ inline TileDesc load_tile_desc(const TileDesc *tiles, int i)
     return TileDesc{(int16_t)(raw & 0xFFFFu), (int16_t)((raw >> 16) & 0xFFFFu), (int16_t)((raw >> 32) & 0xFFFFu), 0};
 }
 
-constexpr int kSteerMaxBreaks = 256; // LDS copy of the steering table's break points in the tile describe kernel (222 today)
+constexpr int kSteerMaxBreaks = 224; // LDS copy of the steering table's break points in the tile describe kernel (222 today)
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 __device__ inline us2 U2(uint32_t v) { return __builtin_bit_cast(us2, v); }
@@ -1366,8 +1366,8 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
     // instructions per keypoint, and the scalar unit issues one instruction per SIMD turn like the vector ALU
     __shared__ uint32_t s_kxy[64], s_kc0[64], s_kslot[64];
     __shared__ int s_mom[128];                               // their moments: m10, m01
-    __shared__ float s_ang[64], s_cos[64], s_sin[64];        // angle and steering (cos, sin)
-    __shared__ int s_kiv[64];                                // interval of the orientation in the steering table (TAB)
+    __shared__ float s_ang[64], s_cos[R == 15 ? 1 : 64], s_sin[R == 15 ? 1 : 64]; // angle and steering (cos, sin: only without the table)
+    __shared__ uint8_t s_kiv[64];                            // interval of the orientation in the steering table (TAB; < 256)
     __shared__ float s_breaks[R == 15 ? kSteerMaxBreaks : 1]; // the table's break points: the bisection of the angle lanes reads LDS
                                                               // (from global memory its 10 dependent loads were 15 % of the kernel)
     __shared__ int s_nkp, s_cursor;
@@ -1582,11 +1582,11 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
             if (TAB) { // interval = number of break points <= the orientation: branch-free bisection
                 int pos = 0;
 #pragma unroll
-                for (int step = kSteerMaxBreaks / 2; step > 0; step >>= 1) {
+                for (int step = 128; step > 0; step >>= 1) { // (kSteerMaxBreaks <= 255)
                     const int t = pos + step;
                     if (t <= steer.n_breaks && s_breaks[t - 1] <= ang) pos = t;
                 }
-                s_kiv[lane] = pos;
+                s_kiv[lane] = (uint8_t)pos;
             }
             *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(records + (size_t)f * g.cap) + s_kslot[lane] + 16) = __float_as_uint(ang);
         }
@@ -1609,7 +1609,7 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
         // waits for them inside the loop, four s_waitcnt per keypoint.
         const uint32_t my_c0 = s_kc0[lane], my_roff = s_kslot[lane];
         const uint32_t my_cos = TAB ? 0u : __float_as_uint(s_cos[lane]), my_sin = TAB ? 0u : __float_as_uint(s_sin[lane]);
-        const int my_iv = TAB ? s_kiv[lane] : 0;
+        const int my_iv = TAB ? (int)s_kiv[lane] : 0;
         if (!TAB) {
 #pragma unroll
             for (int r = 0; r < 4; r++) asm volatile("" ::"v"(pat[r].x), "v"(pat[r].y), "v"(pat[r].z), "v"(pat[r].w));
@@ -2506,7 +2506,7 @@ int orbfe_create(const orbfe_config *cfg, orbfe_ctx **out)
             std::vector<int16_t> off;
             build_steer_table(TileGeom<15>::kPitch, &br, &off, &ctx->steer_central, ctx->steer_sched_mask);
             ctx->n_steer_breaks = (int)br.size();
-            if (ctx->n_steer_breaks > kSteerMaxBreaks) e = hipErrorInvalidValue; // (222 today; the kernel's LDS copy holds 256)
+            if (ctx->n_steer_breaks > kSteerMaxBreaks) e = hipErrorInvalidValue; // (222 today; the kernel's LDS copy holds 224)
             if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_steer_breaks, (br.size() + 1) * sizeof(float));
             if (e == hipSuccess) e = hipMemcpy(ctx->d_steer_breaks, br.data(), br.size() * sizeof(float), hipMemcpyHostToDevice);
             if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_steer_table, off.size() * sizeof(int16_t));
