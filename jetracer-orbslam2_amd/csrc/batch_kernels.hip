@@ -168,7 +168,8 @@ pyramid_fused_kernel(DeviceGeom g, uint8_t *__restrict__ pyr, const uint8_t *__r
             yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
             const uint32_t *p = reinterpret_cast<const uint32_t *>(src + (size_t)yy * src_pitch + (RGB ? 3 : 1) * xc);
 #pragma unroll
-            for (int j = 0; j < (RGB ? 3 : 1); j++) rowv[k][j] = p[j];
+            // (streaming loads: a source frame is read exactly once)
+            for (int j = 0; j < (RGB ? 3 : 1); j++) rowv[k][j] = __builtin_nontemporal_load(p + j);
         }
     }
     // horizontal 1-2-1 sums of input row yy, as (even pixels, odd pixels) 16-bit lane pairs
