@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- ORB front-end throughput on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode c2|ref|c3|c4|c5|match] [--scene dense|survey]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode c2|ref|c3|c4|c5|match|align] [--scene dense|survey]
 
 One "step" = one pass of the hot path over one batch of synthetic frames already resident in HBM:
 orbfe_extract (blur + pyramid -> fused FAST/NMS -> selection -> orientation + rBRIEF -> 52-byte
@@ -25,6 +25,9 @@ Modes (BASELINE.json configs):
   match  SURVEY.md 8d's matcher microbench: nA = nB in {405, 2000, 8192}, random 256-bit descriptors
        (C3's reference shape, C2/C3's budget, C5's), brute force 256-bit and the reference's 32-bit /
        +-2 px window form; one JSON line with Gpairs/s and the MFMA fraction per size.  1 GPU.
+
+  align  SURVEY.md 8f-2's producing half: orbfe_align_depth_batch (depth -> colour camera, cuda-align.cu:366-399) over
+       1024 RealSense-shaped 848x480 depth frames per call, D435-like rig; HBM roofline on 6 B per pixel.  1 GPU.
 
 Multi-GPU: one process per GPU.  Under torchrun (WORLD_SIZE set) this process is one rank; with
 --gpus N > 1 and no WORLD_SIZE the parent starts N child ranks itself BEFORE touching the GPU and
@@ -329,12 +332,100 @@ def match_microbench(args, torch, np, orbfe, dev, json_out):
     json_out.flush()
 
 
+def align_bench(args, torch, np, orbfe, dev, json_out):
+    """--mode align: SURVEY.md 8f-2's producing half, orbfe_align_depth_batch (cuda-align.cu:366-399), on RealSense-shaped
+    848x480 depth frames with a D435-like rig (synth.rig('d435')).  A step = one call over `batch` frames resident in HBM.
+    Algorithmic bytes: 2 B read + 4 B written per pixel; the kernel is HBM-bound in principle."""
+    import ctypes as C
+    from orbfe import synth
+    w, h = 848, 480
+    B = args.batch or 1024
+    n_distinct = max(1, min(args.distinct, B, 32))
+    base = synth.depth_frames(w, h, n_distinct, first_index=500)
+    d, o, e, scale = synth.rig("d435", w, h)
+    mk = lambda t: orbfe.Intrinsics(t[0], t[1], t[2], t[3], t[4], t[5], t[6], (C.c_float * 5)(*t[7]))
+    di, oi = mk(d), mk(o)
+    ex = orbfe.Extrinsics((C.c_float * 9)(*e[0]), (C.c_float * 3)(*e[1]))
+    src = torch.from_numpy(base.view(np.int16)).to(dev)[torch.arange(B, device=dev) % n_distinct].contiguous()
+    out = torch.zeros((B, h * w), dtype=torch.int32, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+
+    def call():
+        orbfe.check(orbfe.lib().orbfe_align_depth_batch(out.data_ptr(), w * h, src.data_ptr(), w * h, B, scale, C.byref(di),
+                                                        C.byref(oi), C.byref(ex), s))
+    for _ in range(max(args.warmup, 3)):
+        call()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms = e0.elapsed_time(e1) / args.steps
+    ab = 6.0 * w * h * B
+    covered = float((out[:n_distinct] != 0).float().mean().item())
+    prof = {}
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("align", {})
+    except Exception:
+        prof = {}
+    stale = not prof or prof.get("csrc_sha256") != orbfe.source_hash()
+    traffic = None if stale else prof.get("align", 0.0) * B / float(prof.get("batch", B))
+    res = {"metric": "depth frames aligned to the colour camera per second (align_depth_to_other), 848x480",
+           "value": B * args.steps / elapsed, "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 3),
+           "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32 (projection arithmetic) / u16 -> u32 (depth)", "data": "synthetic",
+           "config": {"workload": "align_depth_to_other over %d depth frames 848x480 per call, D435-like rig (depth 87 deg, colour 69 deg, "
+                                  "15 mm baseline), 15 %% holes" % B, "mode": "align", "frames_per_gpu_per_step": B,
+                      "distinct_frames_per_rank": n_distinct, "frames_per_launch": int(os.environ.get("ORBFE_ALIGN_CHUNK", "64")),
+                      "output_pixels_covered": covered},
+           "pixels_per_s": B * w * h * args.steps / elapsed,
+           "roofline": {"bound": "hbm", "achieved": ab / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
+                        "kernel": "align_fill_kernel + align_splat_kernel (one call = ceil(frames / frames_per_launch) launches of each)",
+                        "algorithmic_bytes_per_launch": ab, "avg_launch_ms": ms,
+                        "note": "algorithmic bytes = 2 B read + 4 B written per pixel (VERDICT r3 item 3); time = HIP events around "
+                                "the timed calls on the work stream; `launch` here = one orbfe_align_depth_batch call",
+                        "pmc": {"stale": stale}},
+           "cpu_baseline": None}
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle
+        from concurrent.futures import ThreadPoolExecutor
+        cores, affinity, quota = cpu_share()
+        omk = lambda t: oracle.Intrinsics(t[0], t[1], t[2], t[3], t[4], t[5], t[6], (C.c_float * 5)(*t[7]))
+        odi, ooi = omk(d), omk(o)
+        oex = oracle.Extrinsics((C.c_float * 9)(*e[0]), (C.c_float * 3)(*e[1]))
+
+        def one(i):
+            oracle.align_depth_to_other(base[i % n_distinct], scale, w, h, odi, ooi, oex)
+
+        def run(threads, seconds):
+            n, t0 = 0, time.perf_counter()
+            with ThreadPoolExecutor(threads) as tp:
+                while time.perf_counter() - t0 < seconds:
+                    list(tp.map(one, range(n, n + 4 * threads)))
+                    n += 4 * threads
+            return n / (time.perf_counter() - t0), n, time.perf_counter() - t0
+        v1, n1, t1 = run(1, 4.0)
+        vm, nm, tm = run(cores, 8.0)
+        res["cpu_baseline"] = {"value": vm, "unit": "frames/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+                               "single_thread": {"value": v1, "unit": "frames/s", "cores": 1},
+                               "sample": "%d frames by the CPU oracle (the reference's four launches restated, int2 map included) on %d "
+                                         "threads in %.1f s, %d on 1 thread in %.1f s" % (nm, cores, tm, n1, t1)}
+    json_out.write(json.dumps(res) + "\n")
+    json_out.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", choices=sorted(MODES) + ["match"], default="c2")
+    ap.add_argument("--mode", choices=sorted(MODES) + ["match", "align"], default="c2")
     ap.add_argument("--batch", type=int, default=0, help="frames per GPU per step (c2/ref/c3), total frames (c4); "
                                                            "0 = the mode's default")
     ap.add_argument("--scene", choices=("dense", "survey"), default="dense")
@@ -434,6 +525,11 @@ def main():
             sys.exit("bench.py: --mode match is a single-GPU microbench")
         match_microbench(args, torch, np, orbfe, dev, json_out)
         return
+    if args.mode == "align":
+        if world != 1:
+            sys.exit("bench.py: --mode align is a single-GPU bench (frames are independent: N GPUs = N replicas)")
+        align_bench(args, torch, np, orbfe, dev, json_out)
+        return
     m = MODES[args.mode]
     w, h = m["width"], m["height"]
     total = args.batch or m["batch"]
@@ -478,9 +574,10 @@ def main():
         if not args.exact_gather:  # rank 0 extracts straight into its own block of the gathered arrays: no local copy
             recs = [gather_out[b][0][0] for b in range(2)]
             cnts = [gather_out[b][1][0] for b in range(2)]
-    state = dict(frames=None, step=0, tickets=[0, 0], pending=[None, None], events=[], prewarm=0)
+    state = dict(frames=None, step=0, tickets=[0, 0], pending=[None, None], events=[], prewarm=0, ctx=ctx)
 
     def run_step(record, do_gather):
+        ctx = state["ctx"]  # the context of this run (extras time other configurations on the same buffers)
         b = state["step"] & 1
         frames = state["frames"][state["step"] % len(state["frames"])]  # --rotate: another resident batch every step
         state["step"] += 1
@@ -610,6 +707,33 @@ def main():
                                     "frames_per_s": r3["frames_total"] * args.steps / r3["elapsed"],
                                     "keypoints_per_frame": r3["kp_total"] / max(r3["frames_total"], 1)}
         del frames2
+        if args.mode == "c2" and world == 1:
+            # The corrected EXT modes on the same step.  The headline is the reference's quirk-parity
+            # regime: orientation in radians used as degrees (Q7), description always on level 0 (Q10).  The 222-break
+            # orientation table of the tile describe kernel exists ONLY there (|theta| <= 0.055 rad); angle_in_radians = 1
+            # (real rotation) runs the arithmetic loop with a 19-px halo, descriptor_level = 1 (scale-aware) describes on the
+            # level that won the cell.  Same frames, same buffers, one context at a time.
+            fixed = {}
+            for name, kw in (("descriptor_level", dict(descriptor_level=1)), ("angle_in_radians", dict(angle_in_radians=1)),
+                             ("both", dict(descriptor_level=1, angle_in_radians=1))):
+                state["ctx"] = None
+                c2 = orbfe.Context(w, h, max_batch=max(B, 1), device=local_rank, **dict(m["cfg"], **kw))
+                state["ctx"] = c2
+                rr = timed(frames, False, True)
+                st_ms = {k: 0.0 for k in ("pyramid", "detect", "describe", "match")}
+                for ev in rr["events"]:
+                    for i, k in enumerate(st_ms):
+                        st_ms[k] += ev[i].elapsed_time(ev[i + 1])
+                fixed[name] = {"value": rr["kp_total"] * args.steps / rr["elapsed"], "unit": "keypoints/s",
+                               "ms_per_step": rr["elapsed"] / args.steps * 1e3,
+                               "stage_ms": {k: v / max(len(rr["events"]), 1) for k, v in st_ms.items()},
+                               "keypoints_per_frame": rr["kp_total"] / max(rr["frames_total"], 1),
+                               "kernels": c2.dispatch_info(max(B, 1), mm["mode"], mm["window"])["describe"]}
+                c2.close()
+            state["ctx"] = ctx
+            fixed["note"] = ("the headline `value` is the reference's quirk-parity regime (angle_in_radians = 0, descriptor_level "
+                             "= 0); these are the same step with the quirks fixed (orbfe_config), timed the same way")
+            extras["fixed_modes"] = fixed
 
     out = None
     if rank == 0:
@@ -668,11 +792,12 @@ def main():
                 e["valu"] = {"bound": "valu", "unit": "Tlane-op/s", "achieved": ach, "peak": VALU_PEAK_TLANEOPS,
                              "frac": ach / VALU_PEAK_TLANEOPS, "wave_instructions_per_launch": valu_counts[k] * scale,
                              "lane_ops_per_level0_pixel": valu_counts[k] * scale * 64 / (B * w * h)}
-                # share of SIMD cycles with a VALU instruction executing (SQ_ACTIVE_INST_VALU, same PMC pass): the
-                # lane-op fraction prices every instruction at full rate, the mix here is largely half-rate
-                busy = prof.get("valu_pipe_busy", {}).get(k)
+                # SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles: the counter charges every vector instruction one quad-cycle, but a
+                # full-rate instruction retires in 2.76 cycles on this chip, so this is an ISSUE COUNT per
+                # SIMD-cycle, not a busy fraction: it can exceed 1 (detect: 1.06)
+                busy = prof.get("valu_issue_quad_cycles_per_simd_cycle", prof.get("valu_pipe_busy", {})).get(k)
                 if busy is not None:
-                    e["valu"]["pipe_busy"] = busy
+                    e["valu"]["issue_quad_cycles_per_simd_cycle"] = busy
             per_stage[k] = e
         if mfma_match and "match" in per_stage:
             # the 256-bit matcher runs on the matrix cores: 2 x 256 flop per pair on e2m1 operands,
@@ -686,7 +811,25 @@ def main():
         # The tier's declared roofline is HBM: `roofline.frac` = algorithmic bytes of the dominant kernel / its launch
         # time / 8 TB/s.  What the counters show limits that kernel (vector-instruction issue for detect and describe,
         # the matrix cores for the brute-force matcher) sits beside it as named sub-objects, never in `frac`.
-        limiter = "valu" if dom in ("detect", "describe") else ("mfma" if dom == "match" and mfma_match else "hbm")
+        # `limiter` is read from the counters of THIS build, not assumed from the stage's name: the largest of
+        #   hbm  = PMC traffic / launch time / 6.29 TB/s (what a plain copy reaches on this chip),
+        #   valu = vector-instruction issue quad-cycles per SIMD-cycle (capped at 1),
+        #   mfma = matrix-core flop fraction of the dense FP4 peak;  null when there are no PMC passes for this build
+        def limiter_of(e):
+            util = {}
+            if e.get("traffic"):
+                util["hbm"] = e["traffic"] / (e["ms"] * 1e-3) / 1e9 / 6290.0
+            v = (e.get("valu") or {}).get("issue_quad_cycles_per_simd_cycle")
+            if v is not None:
+                util["valu"] = min(v, 1.0)
+            if e.get("mfma"):
+                util["mfma"] = e["mfma"]["frac"]
+            if "hbm" not in util or "valu" not in util:
+                return None, util
+            return max(util, key=util.get), util
+        for e in per_stage.values():
+            e["limiter"], e["limiter_utilisation"] = limiter_of(e)
+        limiter = per_stage[dom]["limiter"]
         roof = {"bound": "hbm", "achieved": per_stage[dom]["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": per_stage[dom]["frac"], "traffic": per_stage[dom]["traffic"],
                 "kernel": kernels[dom], "stage": dom, "algorithmic_bytes_per_launch": ab[dom] * B,
@@ -694,8 +837,9 @@ def main():
                 "limiter": limiter, "valu": per_stage[dom].get("valu"), "mfma": per_stage[dom].get("mfma"),
                 "pmc": pmc,
                 "note": "frac = algorithmic bytes / launch time / 8 TB/s for the kernel with the largest share of the step "
-                        "(HIP events on the work stream inside the timed region); `limiter` names what the PMC counters show "
-                        "bounds it, with that roof in `valu` / `mfma` (DESIGN.md section 4)",
+                        "(HIP events on the work stream inside the timed region); `limiter` = the most utilised of HBM (PMC traffic "
+                        "vs the 6.29 TB/s a copy reaches), VALU issue and MFMA, from the PMC passes of this build (null without "
+                        "them), with that roof in `valu` / `mfma` (DESIGN.md section 4)",
                 "stages": per_stage}
         elapsed = R["elapsed"]
         ms_step = elapsed / args.steps * 1e3
@@ -747,7 +891,10 @@ def main():
                              "bytes_shipped_per_nonroot_rank_per_step": rec_bytes if use_gather else 0,
                              "root_ingress_bytes_per_step": rec_bytes * (world - 1) if use_gather else 0,
                              "per_link_GBps_needed_at_this_step_time": (rec_bytes / (ms_step * 1e-3) / 1e9) if use_gather else 0.0,
-                             "xgmi_link_peak_GBps": 153.0, "links_per_gpu": 7,
+                             # a gather moves data ONE way over each non-root rank's own link to the root: 153.6 GB/s per
+                             # link is the bidirectional figure, a direction offers half of it
+                             "xgmi_link_peak_GBps_one_way": 76.8, "xgmi_link_peak_GBps_bidirectional": 153.6, "links_per_gpu": 7,
+                             "link_utilisation_one_way": ((rec_bytes / (ms_step * 1e-3) / 1e9) / 76.8) if use_gather else 0.0,
                              "note": "fixed stride ships cap records per frame whatever the counts; the root's own block is written "
                                      "in place (no copy).  Hardware status: the world > 1 branch of liborbfe_dist.so has not run on "
                                      "a multi-GPU node of the build pool (world = 1 and gloo rehearsals only)" }

@@ -1,9 +1,13 @@
 // match_port.cpp -- the two-frame part of the reference's SlamGpuPipeline::buildStream written against
-// compat/jetracer_compat.hpp: per frame rgb_to_grayscale .. calc_orb (buildStream.cpp:399-466) and
-// keypoint_pixel_to_point (:468-481), then match_keypoints(current, previous, 2, 4, T, ...) exactly as
-// :545-556 calls it, with the reference's slam_frame_t (types.h:25-65).
+// compat/jetracer_compat.hpp: per frame align_depth_to_other on its own stream (buildStream.cpp:376-394),
+// rgb_to_grayscale .. calc_orb (:399-466) and keypoint_pixel_to_point on the aligned depth (:468-481), then
+// match_keypoints(current, previous, 2, 4, T, ...) exactly as :545-556 calls it, with the reference's slam_frame_t
+// (types.h:25-65).
 //
-//   match_port <width> <height> <rgbA.bin> <rgbB.bin> <depth_u32.bin> <out.bin>
+//   match_port <width> <height> <rgbA.bin> <rgbB.bin> <depth_u16.bin> <rig.bin> <out.bin>
+//
+// rig.bin = orbfe_intrinsics depth | orbfe_intrinsics rgb | orbfe_extrinsics depth->rgb | float depth_scale (the
+// rs2_* structs and get_units() the reference takes from the camera, SlamGpuPipeline.cpp:75-88).
 //
 // out = [int32 n_prev_valid | int32 n_curr_valid | int32 n_matched | keypoints_x u16[n] | keypoints_y u16[n] |
 //        previous_matched double3[n] | current_matched double3[n]] for tests/test_gpu_round2.py to compare
@@ -38,17 +42,28 @@ struct Pipeline { // the per-stream buffers of buildStream.cpp:233-336
     unsigned char *d_rgb_image, *d_gray_image, *d_descriptors_tmp, *d_corner_lut;
     std::size_t rgb_pitch, gray_pitch;
     float *d_keypoints_angle, *d_feature_grid;
-    uint32_t *d_descriptors, *d_aligned_depth;
+    uint32_t *d_descriptors;
+    unsigned int *d_aligned_out;
+    uint16_t *d_depth_in;
+    int2 *d_pixel_map;
     float2 *d_pos;
     float *d_score;
     int *d_level, *d_valid_keypoints_num;
     std::vector<pyramid_t> pyramid;
-    orbfe_intrinsics rgb_intrin;
-    hipStream_t stream;
+    orbfe_intrinsics depth_intrin, rgb_intrin;
+    orbfe_extrinsics depth_rgb_extrinsics;
+    float depth_scale;
+    hipStream_t stream, align_stream;
 };
 
-static std::shared_ptr<slam_frame_t> process(Pipeline &p, const std::vector<unsigned char> &h_rgb)
+static std::shared_ptr<slam_frame_t> process(Pipeline &p, const std::vector<unsigned char> &h_rgb,
+                                             const std::vector<uint16_t> &h_depth)
 {
+    // --------------- align depth to RGB (buildStream.cpp:376-394): its own stream, in parallel with the keypoints
+    CHECK(hipMemcpyAsync(p.d_depth_in, h_depth.data(), h_depth.size() * sizeof(uint16_t), hipMemcpyHostToDevice,
+                         p.align_stream));
+    align_depth_to_other(p.d_aligned_out, p.d_depth_in, p.d_pixel_map, p.depth_scale, p.cam_w, p.cam_h, &p.depth_intrin,
+                         &p.rgb_intrin, &p.depth_rgb_extrinsics, p.align_stream);
     CHECK(hipMemcpy2DAsync(p.d_rgb_image, p.rgb_pitch, h_rgb.data(), (size_t)p.cam_w * 3, (size_t)p.cam_w * 3, p.cam_h,
                            hipMemcpyHostToDevice, p.stream));
     rgb_to_grayscale(p.d_gray_image, p.d_rgb_image, p.cam_w, p.cam_h, (int)p.gray_pitch, (int)p.rgb_pitch, p.stream);
@@ -66,21 +81,19 @@ static std::shared_ptr<slam_frame_t> process(Pipeline &p, const std::vector<unsi
     CHECK(hipMalloc((void **)&frame->d_pos, sizeof(float2) * p.keypoints_num));
     CHECK(hipMalloc((void **)&frame->d_points, sizeof(double) * 3 * p.keypoints_num));
     CHECK(hipMalloc((void **)&frame->d_descriptors, sizeof(uint32_t) * p.keypoints_num));
-    detail::check(orbfe_keypoint_pixel_to_point(p.d_aligned_depth, &p.rgb_intrin, p.cam_w, p.cam_h,
-                                                reinterpret_cast<float *>(frame->d_pos),
-                                                reinterpret_cast<const float *>(p.d_pos), p.d_score, frame->d_points,
-                                                frame->d_descriptors, p.d_descriptors, (int)p.keypoints_num,
-                                                p.d_valid_keypoints_num, 0, detail::S(p.stream)),
-                  "keypoint_pixel_to_point");
-    CHECK(hipMemcpyAsync(&frame->h_valid_keypoints_num, p.d_valid_keypoints_num, sizeof(int), hipMemcpyDeviceToHost,
-                         p.stream));
+    // the reference reads d_aligned_out on `stream` and only synchronises align_stream afterwards (:468-487), a race
+    // it gets away with; ordered here
+    CHECK(hipStreamSynchronize(p.align_stream));
+    keypoint_pixel_to_point(p.d_aligned_out, &p.rgb_intrin, p.cam_w, p.cam_h, frame->d_pos, p.d_pos, p.d_score,
+                            frame->d_points, frame->d_descriptors, p.d_descriptors, (int)p.keypoints_num,
+                            &frame->h_valid_keypoints_num, p.d_valid_keypoints_num, p.stream);
     CHECK(hipStreamSynchronize(p.stream));
     return frame;
 }
 
 int main(int argc, char **argv)
 {
-    if (argc != 7) return 1;
+    if (argc != 8) return 1;
     Pipeline p;
     p.cam_w = std::atoi(argv[1]);
     p.cam_h = std::atoi(argv[2]);
@@ -94,10 +107,21 @@ int main(int argc, char **argv)
         rgb[i].resize((size_t)p.cam_w * p.cam_h * 3);
         read_file(argv[3 + i], rgb[i].data(), rgb[i].size());
     }
-    std::vector<uint32_t> depth((size_t)p.cam_w * p.cam_h);
-    read_file(argv[5], depth.data(), depth.size() * 4);
+    std::vector<uint16_t> depth((size_t)p.cam_w * p.cam_h);
+    read_file(argv[5], depth.data(), depth.size() * sizeof(uint16_t));
+    struct {
+        orbfe_intrinsics depth, rgb;
+        orbfe_extrinsics depth_to_rgb;
+        float depth_scale;
+    } rig;
+    read_file(argv[6], &rig, sizeof(rig));
+    p.depth_intrin = rig.depth;
+    p.rgb_intrin = rig.rgb;
+    p.depth_rgb_extrinsics = rig.depth_to_rgb;
+    p.depth_scale = rig.depth_scale;
 
     CHECK(hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
+    CHECK(hipStreamCreateWithFlags(&p.align_stream, hipStreamNonBlocking));
     const int grid_cols = (p.cam_w + 31) / 32, grid_rows = (p.cam_h + 31) / 32;
     p.keypoints_num = (std::size_t)grid_cols * grid_rows;
     CHECK(hipMallocPitch((void **)&p.d_rgb_image, &p.rgb_pitch, (size_t)p.cam_w * 3, p.cam_h));
@@ -107,9 +131,10 @@ int main(int argc, char **argv)
     CHECK(hipMalloc((void **)&p.d_descriptors, p.keypoints_num * sizeof(uint32_t)));
     CHECK(hipMalloc((void **)&p.d_corner_lut, 64 * 1024));
     CHECK(hipMalloc((void **)&p.d_feature_grid, p.keypoints_num * sizeof(float) * 4));
-    CHECK(hipMalloc((void **)&p.d_aligned_depth, depth.size() * 4));
+    CHECK(hipMalloc((void **)&p.d_aligned_out, (size_t)p.cam_w * sizeof(unsigned int) * p.cam_h)); // buildStream.cpp:250-252
+    CHECK(hipMalloc((void **)&p.d_depth_in, (size_t)p.cam_w * sizeof(uint16_t) * p.cam_h));
+    CHECK(hipMalloc((void **)&p.d_pixel_map, (size_t)p.cam_w * sizeof(int2) * p.cam_h * 2));
     CHECK(hipMalloc((void **)&p.d_valid_keypoints_num, sizeof(int)));
-    CHECK(hipMemcpy(p.d_aligned_depth, depth.data(), depth.size() * 4, hipMemcpyHostToDevice));
     p.d_pos = (float2 *)p.d_feature_grid;
     p.d_score = p.d_feature_grid + p.keypoints_num * 2;
     p.d_level = (int *)(p.d_feature_grid + p.keypoints_num * 3);
@@ -120,14 +145,11 @@ int main(int argc, char **argv)
     CHECK(hipMallocPitch((void **)&level.response, &level.response_pitch, level.image_width * sizeof(float),
                          level.image_height));
     p.pyramid.push_back(level);
-    // a RealSense-like colour camera (rs2_intrinsics layout): no distortion
-    p.rgb_intrin = orbfe_intrinsics{p.cam_w, p.cam_h, p.cam_w * 0.5f - 3.25f, p.cam_h * 0.5f + 1.5f, 615.5f, 615.25f, 0,
-                                    {0.f, 0.f, 0.f, 0.f, 0.f}};
     loadPattern();
     fast_gpu_calculate_lut(p.d_corner_lut, FAST_MIN_ARC_LENGTH, p.stream);
 
-    std::shared_ptr<slam_frame_t> previous_frame = process(p, rgb[0]);
-    std::shared_ptr<slam_frame_t> slam_frame = process(p, rgb[1]);
+    std::shared_ptr<slam_frame_t> previous_frame = process(p, rgb[0], depth);
+    std::shared_ptr<slam_frame_t> slam_frame = process(p, rgb[1], depth);
 
     // buildStream.cpp:523-556
     const double T_w2c_prev_curr[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}; // Eigen::Matrix4d::Identity().data()
@@ -138,7 +160,7 @@ int main(int argc, char **argv)
                     &h_keypoints_num_matched, h_curr.data(), h_prev.data(), &p.rgb_intrin, p.stream);
 
     const int n = h_keypoints_num_matched;
-    FILE *f = std::fopen(argv[6], "wb");
+    FILE *f = std::fopen(argv[7], "wb");
     if (!f) return 1;
     const int32_t head[3] = {previous_frame->h_valid_keypoints_num, slam_frame->h_valid_keypoints_num, n};
     std::fwrite(head, 4, 3, f);

@@ -180,6 +180,40 @@ int orbfe_keypoint_pixel_to_point(const uint32_t *d_aligned_depth, const orbfe_i
                                   int keypoints_num, int32_t *d_valid_keypoints_num,
                                   int fix_depth_index, orbfe_stream_t stream);
 
+/* rs2_extrinsics (librealsense2 rs_types.h) as the reference's kernels read it
+ * (src/cuda/cuda-align.cu:112-119): column-major 3x3 rotation, then the translation. */
+typedef struct orbfe_extrinsics {
+    float rotation[9];
+    float translation[3];
+} orbfe_extrinsics;
+
+/* align_depth_to_other, src/cuda/cuda-align.cuh:37-46 (host :366-399; kernels :121-188, :224-280), SURVEY.md 8f-2:
+ * the depth image resampled onto the other (colour) camera's pixel grid -- the d_aligned_out that
+ * orbfe_keypoint_pixel_to_point reads (buildStream.cpp:385, :468).  Every depth pixel with depth != 0 is mapped
+ * twice (corners -0.5 and +0.5: deproject, transform, project, int(v + 0.5f)), and its raw 16-bit depth goes by
+ * minimum into every output pixel of the rectangle between the two images; pixels no rectangle covers read 0.
+ * Same arguments as the reference, with these differences: the three camera structs are HOST pointers read at
+ * call time (the reference passes device copies); d_pixel_map, the reference's int2[2 W H] scratch, is not
+ * touched and may be NULL (map and splat are one kernel; nothing else ever read the map); depth_scale must be
+ * finite.  As in the reference the launch grid is made from image_width / image_height (32 x 32 blocks) while
+ * all bounds come from the intrinsics: depth pixels / output pixels beyond the grid are not read / not reset.
+ * d_depth_in: depth_intrin->width * height uint16, d_aligned_out: other_intrin->width * height uint32, both
+ * contiguous.  Depth model 1 / 3 (the reference asserts) and other model 3 (f-theta: double atan / tan from
+ * libdevice) return ORBFE_ERR_UNSUPPORTED.  Float arithmetic as written, no contraction: parity with the
+ * reference unpinned at the ulp level, bit-exact against the oracle. */
+int orbfe_align_depth_to_other(uint32_t *d_aligned_out, const uint16_t *d_depth_in, void *d_pixel_map,
+                               float depth_scale, int image_width, int image_height,
+                               const orbfe_intrinsics *depth_intrin, const orbfe_intrinsics *other_intrin,
+                               const orbfe_extrinsics *depth_to_other, orbfe_stream_t stream);
+
+/* The same for n_frames depth frames in one call (frame f at d_depth_in + f * in_frame_stride uint16 elements,
+ * its output at d_aligned_out + f * out_frame_stride uint32 elements); the grid covers both images.  One camera
+ * rig, i.e. one set of intrinsics / extrinsics for the whole batch. */
+int orbfe_align_depth_batch(uint32_t *d_aligned_out, size_t out_frame_stride, const uint16_t *d_depth_in,
+                            size_t in_frame_stride, int n_frames, float depth_scale,
+                            const orbfe_intrinsics *depth_intrin, const orbfe_intrinsics *other_intrin,
+                            const orbfe_extrinsics *depth_to_other, orbfe_stream_t stream);
+
 /* kernel_reproject_prev_points, src/cuda/post_processing.cu:72-90 (with project_point_to_pixel_double,
  * :11-43): the prev frame's 3-D points moved by T_w2c_prev_curr (HOST pointer to 16 doubles,
  * column-major as Eigen::Matrix4d) and projected to pixels -- the positions orbfe_match_keypoints takes
@@ -328,6 +362,15 @@ int orbfe_version(void);
  * describe and match kernels by keypoint density, call size and window; bench.py labels its stages from this
  * instead of repeating the conditions).  Host-side only. */
 int orbfe_dispatch_info(const orbfe_ctx *ctx, int n_frames, int mode, int window, char *buf, size_t size);
+/* The pyramid layout orbfe_create builds for `cfg` and the byte range the detection kernel's UNCONDITIONAL tile loads
+ * touch in it (every tile of every level of frames 0 .. max_batch - 1 reads rows y0 - 4 .. y0 + 67, columns
+ * x0 - 4 .. x0 + 67 of its level without range tests): *tile_lo / *tile_hi = lowest / highest byte relative to the
+ * first byte of frame 0, *pyramid_bytes = max_batch frames, *guard_bytes = the band allocated before and after them.
+ * Legal iff -guard <= lo and hi < pyramid + guard; orbfe_create refuses a geometry that violates it.  Host code, needs
+ * no device: tests/test_layout.py runs it over random geometries (a round-3 work-in-progress build faulted exactly
+ * here before the guard bands existed). */
+int orbfe_layout_bounds(const orbfe_config *cfg, long long *tile_lo, long long *tile_hi,
+                        unsigned long long *pyramid_bytes, unsigned long long *guard_bytes, int *n_tiles);
 /* Exhaustive self-check of the orientation -> rotated-pattern table the tile describe kernel uses in the reference's
  * degrees-as-radians regime (angle_in_radians = 0): for EVERY float orientation in [-pi, pi] (both
  * signs, ~2.2e9 values) the table's 512 sample offsets are compared with the arithmetic of orb.cu:12-14, :42-46 as the

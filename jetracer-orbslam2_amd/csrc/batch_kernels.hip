@@ -2379,6 +2379,72 @@ static MatchPath match_path(const orbfe_ctx *ctx, int n_frames, int mode, int wi
     return kMatchValu256;
 }
 
+// ---- the context's pyramid layout and detection tile list, from the configuration alone (no device) --------------
+// guard bands: a detection tile reads rows y0 - 4 .. y0 + 67 and columns x0 - 4 .. x0 + 67 of its level without range
+// tests (what lies outside the image is never used: the validity masks of phase B); inside the buffer that is a
+// neighbouring level or frame, at its two ends it is these bands.
+static_assert(kPxH == kTileH + 8 && kPxW == kTileW + 8 && kPxW % 4 == 0,
+              "the guard bands below are sized for the pixel tile detect_tile_kernel loads: 4-px halo on every side");
+static void layout_of(const orbfe_config *cfg, DeviceGeom *gp, std::vector<TileDesc> *tiles, size_t *guard)
+{
+    DeviceGeom &g = *gp;
+    memset(&g, 0, sizeof(g));
+    g.W = cfg->width;
+    g.H = cfg->height;
+    g.L = cfg->levels;
+    g.cell = cfg->cell;
+    g.cells_x = (g.W + g.cell - 1) / g.cell;
+    g.cells_y = (g.H + g.cell - 1) / g.cell;
+    g.K = g.cells_x * g.cells_y;
+    g.cap = (cfg->max_features > 0 && cfg->max_features < g.K) ? cfg->max_features : g.K;
+    g.threshold = cfg->fast_threshold;
+    g.arc = cfg->min_arc;
+    g.max_features = cfg->max_features;
+    g.angle_in_radians = cfg->angle_in_radians ? 1 : 0;
+    g.descriptor_level = cfg->descriptor_level ? 1 : 0;
+    size_t off = 0;
+    for (int l = 0; l < g.L; l++) {
+        g.lv[l].w = g.W >> l;
+        g.lv[l].h = g.H >> l;
+        g.lv[l].pitch = (int)align_up((size_t)(g.lv[l].w > 0 ? g.lv[l].w : 1), 64);
+        g.lv[l].offset = off;
+        off += align_up((size_t)g.lv[l].pitch * (size_t)(g.lv[l].h > 0 ? g.lv[l].h : 1), 256);
+    }
+    g.frame_stride = off;
+    g.Ld = 0;
+    while (g.Ld < g.L && (g.cell >> g.Ld) > 0 && g.lv[g.Ld].w > 0 && g.lv[g.Ld].h > 0) g.Ld++;
+    tiles->clear();
+    for (int l = 0; l < g.Ld; l++) {
+        if (g.lv[l].w < 7 || g.lv[l].h < 7) continue; // no pixel is >= 3 from every border
+        const int tx = (g.lv[l].w + kTileW - 1) / kTileW, ty = (g.lv[l].h + kTileH - 1) / kTileH;
+        for (int y = 0; y < ty; y++)
+            for (int x = 0; x < tx; x++) tiles->push_back(TileDesc{(int16_t)l, (int16_t)x, (int16_t)y, 0});
+    }
+    *guard = align_up((size_t)kPxH * (size_t)g.lv[0].pitch + 256, 256);
+}
+
+// lowest and highest byte, relative to frame 0's level 0 (d_pyr), that the unconditional loads of ANY detection tile of
+// ANY of n_frames frames touch: dword i < kPxH * kPxDw of a tile is row i / kPxDw, group i % kPxDw, at
+// (y0 - 4 + row) * pitch + x0 - 4 + 4 * group of its level (detect_tile_kernel phase A); lanes past the last dword
+// re-load their first one
+static void tile_load_extent(const DeviceGeom &g, const std::vector<TileDesc> &tiles, size_t n_frames, long long *lo, long long *hi)
+{
+    long long mn = 0, mx = -1;
+    bool any = false;
+    for (const TileDesc &t : tiles) {
+        const long long P = g.lv[t.level].pitch, base = (long long)g.lv[t.level].offset;
+        const long long x0 = (long long)t.tx * kTileW, y0 = (long long)t.ty * kTileH;
+        const long long first = base + (y0 - 4) * P + x0 - 4;
+        const long long last = base + (y0 - 4 + kPxH - 1) * P + x0 - 4 + 4 * (kPxDw - 1) + 3;
+        const long long last_f = last + (long long)(n_frames - 1) * (long long)g.frame_stride;
+        if (!any || first < mn) mn = first;
+        if (!any || last_f > mx) mx = last_f;
+        any = true;
+    }
+    *lo = any ? mn : 0;
+    *hi = any ? mx : -1;
+}
+
 #define CTX_FAIL(ctx, code, ...)                                                            \
     do {                                                                                    \
         format_error((ctx) ? (ctx)->err : nullptr, __VA_ARGS__);                            \
@@ -2412,6 +2478,30 @@ void orbfe_default_config(orbfe_config *cfg, int width, int height)
 
 const char *orbfe_last_error(const orbfe_ctx *ctx) { return ctx ? ctx->err : thread_error(); }
 
+int orbfe_layout_bounds(const orbfe_config *cfg, long long *tile_lo, long long *tile_hi, unsigned long long *pyramid_bytes,
+                        unsigned long long *guard_bytes, int *n_tiles)
+{
+    if (!cfg || cfg->width < 8 || cfg->height < 8 || cfg->width > 16384 || cfg->height > 16384 || cfg->levels < 1 ||
+        cfg->levels > kMaxLevels || (cfg->cell != 8 && cfg->cell != 16 && cfg->cell != 32 && cfg->cell != 64) || cfg->max_batch < 1)
+        return ORBFE_ERR_INVALID_ARG;
+    DeviceGeom g;
+    std::vector<TileDesc> tiles;
+    size_t guard = 0;
+    layout_of(cfg, &g, &tiles, &guard);
+    long long lo = 0, hi = -1;
+    tile_load_extent(g, tiles, (size_t)cfg->max_batch, &lo, &hi);
+    if (tile_lo) *tile_lo = lo;
+    if (tile_hi) *tile_hi = hi;
+    if (pyramid_bytes) *pyramid_bytes = (unsigned long long)cfg->max_batch * g.frame_stride;
+    if (guard_bytes) *guard_bytes = guard;
+    if (n_tiles) *n_tiles = (int)tiles.size();
+    // the tile describe kernel's staging clamps every 16-byte chunk into [0, H - 1] x [0, pitch - 16] of its level
+    // (describe_tile_kernel, "stage the tile"): legal iff every level's pitch holds at least one chunk
+    for (int l = 0; l < g.L; l++)
+        if (g.lv[l].pitch < 16 || g.lv[l].pitch % 16 != 0) return ORBFE_ERR_UNSUPPORTED;
+    return ORBFE_OK;
+}
+
 int orbfe_create(const orbfe_config *cfg, orbfe_ctx **out)
 {
     if (!cfg || !out) CTX_FAIL((orbfe_ctx *)nullptr, ORBFE_ERR_INVALID_ARG, "orbfe_create: null argument");
@@ -2440,46 +2530,26 @@ int orbfe_create(const orbfe_config *cfg, orbfe_ctx **out)
     orbfe_ctx *ctx = new orbfe_ctx();
     ctx->cfg = *cfg;
     DeviceGeom &g = ctx->g;
-    memset(&g, 0, sizeof(g));
-    g.W = cfg->width;
-    g.H = cfg->height;
-    g.L = cfg->levels;
-    g.cell = cfg->cell;
-    g.cells_x = (g.W + g.cell - 1) / g.cell;
-    g.cells_y = (g.H + g.cell - 1) / g.cell;
-    g.K = g.cells_x * g.cells_y;
-    g.cap = (cfg->max_features > 0 && cfg->max_features < g.K) ? cfg->max_features : g.K;
-    g.threshold = cfg->fast_threshold;
-    g.arc = cfg->min_arc;
-    g.max_features = cfg->max_features;
-    g.angle_in_radians = cfg->angle_in_radians ? 1 : 0;
-    g.descriptor_level = cfg->descriptor_level ? 1 : 0;
-    size_t off = 0;
-    for (int l = 0; l < g.L; l++) {
-        g.lv[l].w = g.W >> l;
-        g.lv[l].h = g.H >> l;
-        g.lv[l].pitch = (int)align_up((size_t)(g.lv[l].w > 0 ? g.lv[l].w : 1), 64);
-        g.lv[l].offset = off;
-        off += align_up((size_t)g.lv[l].pitch * (size_t)(g.lv[l].h > 0 ? g.lv[l].h : 1), 256);
-    }
-    g.frame_stride = off;
-    g.Ld = 0;
-    while (g.Ld < g.L && (g.cell >> g.Ld) > 0 && g.lv[g.Ld].w > 0 && g.lv[g.Ld].h > 0) g.Ld++;
-
     std::vector<TileDesc> tiles;
-    for (int l = 0; l < g.Ld; l++) {
-        if (g.lv[l].w < 7 || g.lv[l].h < 7) continue; // no pixel is >= 3 from every border
-        const int tx = (g.lv[l].w + kTileW - 1) / kTileW, ty = (g.lv[l].h + kTileH - 1) / kTileH;
-        for (int y = 0; y < ty; y++)
-            for (int x = 0; x < tx; x++) tiles.push_back(TileDesc{(int16_t)l, (int16_t)x, (int16_t)y, 0});
-    }
+    size_t guard = 0;
+    layout_of(cfg, &g, &tiles, &guard);
     ctx->n_tiles = (int)tiles.size();
 
     const size_t B = (size_t)cfg->max_batch;
-    // guard bands: a detection tile reads rows y0 - 4 .. y0 + 67 and columns x0 - 4 .. x0 + 67 of its level without
-    // range tests (what lies outside the image is never used: the validity masks of phase B); inside the buffer that
-    // is a neighbouring level or frame, at its two ends it is these bands
-    const size_t guard = align_up((size_t)(kTileH + 8) * (size_t)g.lv[0].pitch + 256, 256);
+    {
+        // the invariant behind the unconditional tile loads (detect_tile_kernel phase A), checked per geometry on the
+        // host: round 3's work-in-progress form of those loads faulted ("Memory access fault by GPU node-2",
+        // gpurun_out/r3i) because the guard bands were not there yet; tests/test_layout.py runs the same check over
+        // random geometries without a device
+        long long lo = 0, hi = 0;
+        tile_load_extent(g, tiles, B, &lo, &hi);
+        if (lo < -(long long)guard || hi >= (long long)(B * g.frame_stride + guard)) {
+            delete ctx;
+            CTX_FAIL((orbfe_ctx *)nullptr, ORBFE_ERR_UNSUPPORTED,
+                     "orbfe_create: internal: a detection tile would read bytes %lld .. %lld of a pyramid of %zu bytes with "
+                     "%zu-byte guard bands", lo, hi, B * g.frame_stride, guard);
+        }
+    }
     hipError_t e = hipMalloc((void **)&ctx->d_pyr_alloc, B * g.frame_stride + 2 * guard);
     if (e == hipSuccess) e = hipMemset(ctx->d_pyr_alloc, 0, B * g.frame_stride + 2 * guard);
     if (e == hipSuccess) ctx->d_pyr = ctx->d_pyr_alloc + guard;

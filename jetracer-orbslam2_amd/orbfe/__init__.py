@@ -49,6 +49,10 @@ class Intrinsics(C.Structure):  # orbfe_intrinsics == rs2_intrinsics
                 ("fx", C.c_float), ("fy", C.c_float), ("model", C.c_int32), ("coeffs", C.c_float * 5)]
 
 
+class Extrinsics(C.Structure):  # orbfe_extrinsics == rs2_extrinsics
+    _fields_ = [("rotation", C.c_float * 9), ("translation", C.c_float * 3)]
+
+
 class Soa(C.Structure):
     _fields_ = [("d_pos", C.c_void_p), ("d_score", C.c_void_p), ("d_level", C.c_void_p),
                 ("d_angle", C.c_void_p), ("d_desc", C.c_void_p), ("d_desc32", C.c_void_p)]
@@ -80,6 +84,12 @@ _SIGS = {
     "orbfe_keypoint_pixel_to_point": (C.c_int, [C.c_void_p, C.POINTER(Intrinsics), C.c_int, C.c_int, C.c_void_p,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "orbfe_align_depth_to_other": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int,
+                                             C.POINTER(Intrinsics), C.POINTER(Intrinsics), C.POINTER(Extrinsics),
+                                             C.c_void_p]),
+    "orbfe_align_depth_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_float,
+                                          C.POINTER(Intrinsics), C.POINTER(Intrinsics), C.POINTER(Extrinsics),
+                                          C.c_void_p]),
     "orbfe_match_compact": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "orbfe_reproject_points": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(Intrinsics),
@@ -118,6 +128,8 @@ _SIGS = {
     "orbfe_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "orbfe_stream_sync": (C.c_int, [C.c_void_p]),
     "orbfe_dispatch_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+    "orbfe_layout_bounds": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
+                                      C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_int)]),
     "orbfe_selfcheck_steer_table": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
 }
 

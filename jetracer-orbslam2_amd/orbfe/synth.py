@@ -78,3 +78,72 @@ def shifted_pair(width, height, index=0, dx=3, dy=0, **kw):
 def descriptors(n, seed=1):
     """n random 256-bit descriptors as u8 [n, 32]."""
     return splitmix64(BASE_SEED ^ (seed * 0x10001), n * 4).view(np.uint8).reshape(n, 32).copy()
+
+
+# ---- depth frames and camera rigs for align_depth_to_other (SURVEY.md 8f-2) --------------------------------
+def depth_frame(width, height, index=0, n_rects=40, holes=0.15, near=300, far=4000):
+    """One u16 depth frame [height, width] in the units of a D4xx (1 unit = depth_scale metres, normally 1 mm):
+    a slanted background wall `far` units away with +-2 units of noise, n_rects fronto-parallel boxes between
+    `near` and `far`, and a fraction `holes` of invalid pixels (0), half of them as 1..12-pixel horizontal runs
+    (the shadow bands a stereo depth camera leaves beside foreground edges)."""
+    seed = BASE_SEED + 0x2000 + index
+    yy, xx = np.mgrid[0:height, 0:width]
+    img = (far - 0.6 * xx - 0.25 * yy).astype(np.int32)
+    r = splitmix64(seed, 5 * n_rects)
+    for k in range(n_rects):
+        x0 = int(r[5 * k] % np.uint64(width))
+        y0 = int(r[5 * k + 1] % np.uint64(height))
+        rw = 8 + int(r[5 * k + 2] % np.uint64(max(width // 4, 9)))
+        rh = 8 + int(r[5 * k + 3] % np.uint64(max(height // 4, 9)))
+        img[y0:min(y0 + rh, height), x0:min(x0 + rw, width)] = near + int(r[5 * k + 4] % np.uint64(max(far - near, 1)))
+    u = splitmix64(seed, width * height, start=5 * n_rects)
+    img += ((u % np.uint64(5)).astype(np.int32) - 2).reshape(height, width)
+    img = np.clip(img, 1, 65535).astype(np.uint16)
+    sel = ((u >> np.uint64(8)) % np.uint64(10000)).reshape(height, width)
+    img[sel < np.uint64(int(holes * 5000))] = 0
+    starts = np.argwhere((sel >= np.uint64(5000)) & (sel < np.uint64(5000 + int(holes * 5000 / 6))))
+    run = ((u >> np.uint64(24)) % np.uint64(12)).reshape(height, width)
+    for y, x in starts:
+        img[y, x:min(x + 1 + int(run[y, x]), width)] = 0
+    return img
+
+
+def depth_frames(width, height, count, first_index=0, **kw):
+    return np.stack([depth_frame(width, height, first_index + i, **kw) for i in range(count)])
+
+
+def rig(kind, dw, dh, ow=None, oh=None):
+    """(depth intrinsics, other intrinsics, extrinsics, depth_scale) as plain tuples
+    (width, height, ppx, ppy, fx, fy, model, coeffs[5]) / (rotation[9] column-major, translation[3]):
+      'identity'  the same pinhole twice, no motion;
+      'd435'      a D435-like pair: depth 87 deg wide (Brown-Conrady with zero coefficients = no distortion is
+                  applied, model 4), colour 69 deg (inverse Brown-Conrady, model 2, zero coefficients: never used when
+                  projecting), 15 mm baseline and a fraction of a degree of rotation;
+      'distorted' inverse Brown-Conrady on the depth camera (deprojection polynomial, cuda-align.cu:69-77) and
+                  modified Brown-Conrady on the other (projection polynomial, :31-42), 50 mm baseline, 2 degrees;
+      'wild'      30-degree roll, 0.6 m offset: near rectangles leave the frame, a tile's rectangles scatter over
+                  hundreds of pixels (no LDS window holds them), many are one pixel wide."""
+    ow, oh = ow or dw, oh or dh
+    z5 = (0.0,) * 5
+    if kind == "identity":
+        k = (dw, dh, dw * 0.5, dh * 0.5, dw * 0.6, dw * 0.6, 0, z5)
+        return k, (ow, oh) + k[2:], ((1, 0, 0, 0, 1, 0, 0, 0, 1), (0, 0, 0)), 0.001
+    if kind == "d435":
+        d = (dw, dh, dw * 0.5 - 2.3, dh * 0.5 + 1.7, dw * 0.4976, dw * 0.4976, 4, z5)
+        o = (ow, oh, ow * 0.5 + 3.1, oh * 0.5 - 2.2, ow * 0.7266, ow * 0.7261, 2, z5)
+        a, b, c = 0.0031, -0.0042, 0.0017  # small rotation about x, y, z (first order is enough for a test rig)
+        rot = (1.0, c, -b, -c, 1.0, a, b, -a, 1.0)
+        return d, o, (rot, (0.0148, 0.0003, -0.0004)), 0.001
+    if kind == "distorted":
+        d = (dw, dh, dw * 0.5 + 1.2, dh * 0.5 - 0.8, dw * 0.62, dw * 0.618, 2, (0.08, -0.12, 0.0009, -0.0006, 0.03))
+        o = (ow, oh, ow * 0.5 - 2.5, oh * 0.5 + 2.0, ow * 0.68, ow * 0.681, 1, (-0.05, 0.07, -0.0008, 0.0005, -0.01))
+        cs, sn = float(np.cos(np.radians(2.0))), float(np.sin(np.radians(2.0)))
+        rot = (cs, 0.0, -sn, 0.0, 1.0, 0.0, sn, 0.0, cs)  # 2 degrees about y
+        return d, o, (rot, (0.05, -0.004, 0.002)), 0.001
+    if kind == "wild":
+        d = (dw, dh, dw * 0.5, dh * 0.5, dw * 0.5, dw * 0.5, 0, z5)
+        o = (ow, oh, ow * 0.5, oh * 0.5, ow * 0.9, ow * 0.9, 0, z5)
+        cs, sn = float(np.cos(np.radians(30.0))), float(np.sin(np.radians(30.0)))
+        rot = (cs, sn, 0.0, -sn, cs, 0.0, 0.0, 0.0, 1.0)  # 30 degrees about z
+        return d, o, (rot, (0.6, -0.2, 0.1)), 0.001
+    raise ValueError(kind)

@@ -203,6 +203,28 @@ def keypoint_pixel_to_point(depth, intrin, pos, score, desc, fix_depth_index=0):
     return pos_out[:cnt], pts[:cnt], dout[:cnt], cnt
 
 
+class Extrinsics(C.Structure):
+    _fields_ = [("rotation", C.c_float * 9), ("translation", C.c_float * 3)]
+
+
+def align_depth_to_other(depth, depth_scale, image_width, image_height, depth_intrin, other_intrin, extrin,
+                         out_init=None, want_map=False):
+    """depth u16[dh, dw] -> aligned u32[oh, ow] (cuda-align.cu:366-399).  out_init: what the caller's output
+    buffer held before the call (matters only outside the launch grid); default 0xDEADBEEF.
+    Returns (aligned, map int32[2, dh, dw, 2] | None); raises on the models the reference cannot run."""
+    depth = np.ascontiguousarray(depth, dtype=np.uint16)
+    assert depth.shape == (depth_intrin.height, depth_intrin.width)
+    out = np.full((other_intrin.height, other_intrin.width), 0xDEADBEEF, np.uint32) if out_init is None \
+        else np.ascontiguousarray(out_init, dtype=np.uint32).copy()
+    pm = np.full((2,) + depth.shape + (2,), -7, np.int32) if want_map else None
+    rc = lib().oracle_align_depth_to_other(_p(out), _p(depth), _p(pm), C.c_float(depth_scale), image_width,
+                                           image_height, C.byref(depth_intrin), C.byref(other_intrin),
+                                           C.byref(extrin))
+    if rc != 0:
+        raise ValueError("align_depth_to_other: unsupported distortion model")
+    return out, pm
+
+
 def match_keypoints(pos_prev, desc_prev, pos_curr, desc_curr, max_px=2, max_ham=4):
     pos_prev = np.ascontiguousarray(pos_prev, dtype=np.float32).reshape(-1, 2)
     pos_curr = np.ascontiguousarray(pos_curr, dtype=np.float32).reshape(-1, 2)

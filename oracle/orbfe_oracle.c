@@ -680,6 +680,144 @@ int oracle_keypoint_pixel_to_point(const uint32_t *aligned_depth, const oracle_i
     return count;
 }
 
+/* ------------------------------------------------------------------------------------
+ * f2 (the producing half)  align_depth_to_other            src/cuda/cuda-align.cu:366-399
+ *     kernel_map_depth_to_other + kernel_transfer_pixels   :163-188, :121-161
+ *     deproject / transform / project (float)              :57-81, :112-119, :23-54
+ *     kernel_reset_to_max, kernel_depth_to_other, kernel_reset_to_zero   :257-267, :224-255, :269-280
+ * The four launches are restated one after the other, the int2 map included (the reference's
+ * scratch, returned here so that the tests can look at it).  All launches use ONE grid made from
+ * image_width / image_height (32 x 32 threads, ceil-div, :378-380) while every bound inside the
+ * kernels is an intrinsics field, so:
+ *   - a depth pixel is mapped and splatted iff x < min(gx, depth.width), y < min(gy, depth.height),
+ *     gx = 32 ceil(image_width / 32), gy likewise; depth_in and the map are indexed with depth.width;
+ *   - an output pixel is reset to 9999999 (and back to 0 at the end) iff x < min(gx, other.width),
+ *     y < min(gy, other.height); output pixels outside keep min(what the caller left there, splats).
+ * Arithmetic: float, left to right as written, NO contraction (nvcc's default -fmad may fuse; not
+ * observable here: PARITY UNPINNED at the ulp level, as for a8 / a9); `static_cast<int>(v + 0.5f)`
+ * is CUDA's cvt.rzi.s32.f32 -- truncation that SATURATES and maps NaN to 0 (other_point z = 0 gives
+ * inf / NaN pixels, which the reference then treats like any other pair of corners).
+ * The f-theta branch of project_point_to_pixel (:44-50) calls double atan / tan from libdevice: not
+ * restated, a caller with model 3 gets "unsupported" (return -1); deprojecting from model 1 or 3
+ * trips the reference's device asserts (:62-63): -1 as well.
+ * kernel_depth_to_other's atomicMin over a rectangle is order-free: the result is the minimum raw
+ * depth over all depth pixels whose mapped rectangle [p0, p1] covers the output pixel.
+ * ------------------------------------------------------------------------------------ */
+static int cvt_rzi_s32_f32(float f)
+{
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f <= -2147483648.0f) return (int)(-2147483647 - 1);
+    return (int)f;
+}
+
+/* kernel_transfer_pixels for one corner (block_index 0: shift -0.5, 1: +0.5), cuda-align.cu:121-161 */
+static void oracle_transfer_pixel(int32_t *mapped_xy, const oracle_intrinsics *din,
+                                  const oracle_intrinsics *oin, const oracle_extrinsics *e,
+                                  float depth_val, int depth_x, int depth_y, int block_index)
+{
+    ORBFE_NO_CONTRACT
+    const float shift = block_index ? 0.5f : -0.5f;
+    mapped_xy[0] = -1;
+    mapped_xy[1] = -1;
+    if (depth_val != 0) {
+        const float depth_pixel[2] = {(float)depth_x + shift, (float)depth_y + shift};
+        float depth_point[3], other_point[3], other_pixel[2];
+        /* deproject_pixel_to_point :57-81 */
+        float x = (depth_pixel[0] - din->ppx) / din->fx;
+        float y = (depth_pixel[1] - din->ppy) / din->fy;
+        if (din->model == 2) { /* RS2_DISTORTION_INVERSE_BROWN_CONRADY */
+            const float *c = din->coeffs;
+            const float r2 = x * x + y * y;
+            float f = 1 + c[0] * r2;
+            f = f + c[1] * r2 * r2;
+            f = f + c[4] * r2 * r2 * r2;
+            float ux = x * f + 2 * c[2] * x * y;
+            ux = ux + c[3] * (r2 + 2 * x * x);
+            float uy = y * f + 2 * c[3] * x * y;
+            uy = uy + c[2] * (r2 + 2 * y * y);
+            x = ux;
+            y = uy;
+        }
+        depth_point[0] = depth_val * x;
+        depth_point[1] = depth_val * y;
+        depth_point[2] = depth_val;
+        /* transform_point_to_point :112-119 (rotation column-major) */
+        for (int i = 0; i < 3; i++) {
+            float t = e->rotation[i] * depth_point[0] + e->rotation[3 + i] * depth_point[1];
+            t = t + e->rotation[6 + i] * depth_point[2];
+            t = t + e->translation[i];
+            other_point[i] = t;
+        }
+        /* project_point_to_pixel :23-54 */
+        x = other_point[0] / other_point[2];
+        y = other_point[1] / other_point[2];
+        if (oin->model == 1) { /* RS2_DISTORTION_MODIFIED_BROWN_CONRADY */
+            const float *c = oin->coeffs;
+            const float r2 = x * x + y * y;
+            float f = 1 + c[0] * r2;
+            f = f + c[1] * r2 * r2;
+            f = f + c[4] * r2 * r2 * r2;
+            x *= f;
+            y *= f;
+            float dx = x + 2 * c[2] * x * y;
+            dx = dx + c[3] * (r2 + 2 * x * x);
+            float dy = y + 2 * c[3] * x * y;
+            dy = dy + c[2] * (r2 + 2 * y * y);
+            x = dx;
+            y = dy;
+        }
+        other_pixel[0] = x * oin->fx + oin->ppx;
+        other_pixel[1] = y * oin->fy + oin->ppy;
+        mapped_xy[0] = cvt_rzi_s32_f32(other_pixel[0] + 0.5f);
+        mapped_xy[1] = cvt_rzi_s32_f32(other_pixel[1] + 0.5f);
+    }
+}
+
+int oracle_align_depth_to_other(uint32_t *aligned_out, const uint16_t *depth_in, int32_t *pixel_map,
+                                float depth_scale, int image_width, int image_height,
+                                const oracle_intrinsics *din, const oracle_intrinsics *oin,
+                                const oracle_extrinsics *e)
+{
+    if (din->model == 1 || din->model == 3 || oin->model == 3) return -1;
+    const int gx = 32 * ((image_width + 31) / 32), gy = 32 * ((image_height + 31) / 32);
+    const int dw = din->width, dh = din->height, ow = oin->width, oh = oin->height;
+    const int mx = gx < dw ? gx : dw, my = gy < dh ? gy : dh; /* depth pixels the grid reaches */
+    const int rx = gx < ow ? gx : ow, ry = gy < oh ? gy : oh; /* output pixels the grid reaches */
+    const size_t depth_size = (size_t)dw * dh;
+    int32_t *map = pixel_map ? pixel_map : (int32_t *)malloc(depth_size * 2 * 2 * sizeof(int32_t));
+    /* kernel_map_depth_to_other, blockIdx.z = 0, 1 */
+    for (int z = 0; z < 2; z++)
+        for (int y = 0; y < my; y++)
+            for (int x = 0; x < mx; x++) {
+                const size_t i = (size_t)y * dw + x;
+                const float depth_val = (float)depth_in[i] * depth_scale;
+                oracle_transfer_pixel(map + 2 * ((size_t)z * depth_size + i), din, oin, e, depth_val, x, y, z);
+            }
+    /* kernel_reset_to_max */
+    for (int y = 0; y < ry; y++)
+        for (int x = 0; x < rx; x++) aligned_out[(size_t)y * ow + x] = 9999999u;
+    /* kernel_depth_to_other */
+    for (int y = 0; y < my; y++)
+        for (int x = 0; x < mx; x++) {
+            const size_t i = (size_t)y * dw + x;
+            const int32_t *p0 = map + 2 * i, *p1 = map + 2 * (depth_size + i);
+            if (p0[0] < 0 || p0[1] < 0 || p1[0] >= ow || p1[1] >= oh) continue;
+            const uint32_t new_val = depth_in[i];
+            for (int v = p0[1]; v <= p1[1]; v++)
+                for (int u = p0[0]; u <= p1[0]; u++) {
+                    uint32_t *o = aligned_out + (size_t)v * ow + u;
+                    if (new_val < *o) *o = new_val; /* atomicMin */
+                }
+        }
+    /* kernel_reset_to_zero */
+    for (int y = 0; y < ry; y++)
+        for (int x = 0; x < rx; x++)
+            if (aligned_out[(size_t)y * ow + x] == 9999999u) aligned_out[(size_t)y * ow + x] = 0;
+    if (!pixel_map) free(map);
+    return 0;
+}
+
 /* EXT C.9: brute-force 256-bit Hamming, lexicographic (dist, idx) minimum.
  * 256 bits = 4 x 64-bit popcounts.  The loop is instantiated twice, once for the hardware popcnt
  * instruction (picked at run time when the host has it) so that the CPU baseline is a fair port

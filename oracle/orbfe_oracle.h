@@ -90,6 +90,18 @@ int oracle_keypoint_pixel_to_point(const uint32_t *aligned_depth, const oracle_i
                                    const float *pos_in, const float *score, double *points,
                                    uint32_t *desc_out, const uint32_t *desc_in, int n,
                                    int fix_depth_index);
+/* f2, the producing half: align_depth_to_other, cuda-align.cu:121-188, :224-280, :366-399.
+ * rs2_extrinsics as the kernels read it (:112-119): column-major 3x3 rotation, translation.
+ * pixel_map (optional): int2[2 * depth.width * depth.height], the reference's scratch.
+ * Returns 0, or -1 for the models the reference asserts on / needs libdevice double atan for. */
+typedef struct oracle_extrinsics {
+    float rotation[9];
+    float translation[3];
+} oracle_extrinsics;
+int oracle_align_depth_to_other(uint32_t *aligned_out, const uint16_t *depth_in, int32_t *pixel_map,
+                                float depth_scale, int image_width, int image_height,
+                                const oracle_intrinsics *depth_intrin, const oracle_intrinsics *other_intrin,
+                                const oracle_extrinsics *depth_to_other);
 int oracle_match_keypoints(const float *pos_prev, const uint32_t *desc_prev, int n_prev,
                            const float *pos_curr, const uint32_t *desc_curr, int n_curr,
                            int max_px, int max_ham, int32_t *match_idx /*[n_prev], -1 = none*/);

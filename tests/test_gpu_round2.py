@@ -281,40 +281,45 @@ def test_reproject_points(gpu, oracle_mod, model):
 
 
 def test_cpp_match_port(gpu, oracle_mod, tmp_path):
-    """examples/match_port.cpp: two frames through the reference's call sequence incl.
-    keypoint_pixel_to_point and match_keypoints(current, previous, 2, 4, T, ...) with slam_frame_t
-    (buildStream.cpp:399-556) via compat/jetracer_compat.hpp; outputs must equal the oracle's."""
+    """examples/match_port.cpp: two frames through the reference's call sequence incl. align_depth_to_other on its own
+    stream, keypoint_pixel_to_point on the aligned depth and match_keypoints(current, previous, 2, 4, T, ...) with
+    slam_frame_t (buildStream.cpp:376-556) via compat/jetracer_compat.hpp; outputs must equal the oracle's."""
     import os
     import subprocess
+    from test_align_oracle import extr, intr
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "examples", "match_port")
     assert os.path.exists(exe), "run __graft_entry__.build() first"
+    torch, orbfe = gpu
     w, h = 848, 480
     a, b = synth.shifted_pair(w, h, 77, dx=1, dy=0, **synth.DENSE)
     rgbs = [np.stack([g, g, g], -1) for g in (a, b)]
-    rng = np.random.default_rng(3)
-    depth = rng.integers(0, 4000, size=(h, w)).astype(np.uint32)
-    depth[rng.random((h, w)) < 0.2] = 0
-    paths = [str(tmp_path / n) for n in ("a.bin", "b.bin", "depth.bin", "out.bin")]
+    depth = synth.depth_frame(w, h, 3)
+    d, o, e, scale = synth.rig("d435", w, h)
+    paths = [str(tmp_path / n) for n in ("a.bin", "b.bin", "depth.bin", "rig.bin", "out.bin")]
     rgbs[0].tofile(paths[0]); rgbs[1].tofile(paths[1]); depth.tofile(paths[2])
+    with open(paths[3], "wb") as f:  # orbfe_intrinsics x 2, orbfe_extrinsics, float: as the C structs lie in memory
+        f.write(bytes(intr(orbfe, d)) + bytes(intr(orbfe, o)) + bytes(extr(orbfe, e)) + np.float32(scale).tobytes())
     subprocess.check_call([exe, str(w), str(h), *paths])
-    raw = np.fromfile(paths[3], np.uint8)
+    raw = np.fromfile(paths[4], np.uint8)
     nprev, ncurr, n = raw[:12].view(np.int32)
     kx = raw[12:12 + 2 * n].view(np.uint16)
     ky = raw[12 + 2 * n:12 + 4 * n].view(np.uint16)
     pm = raw[12 + 4 * n:12 + 4 * n + 24 * n].view(np.float64).reshape(n, 3)
     cm = raw[12 + 28 * n:12 + 52 * n].view(np.float64).reshape(n, 3)
     # the oracle, call by call
-    intr = oracle_mod.Intrinsics(w, h, w * 0.5 - 3.25, h * 0.5 + 1.5, 615.5, 615.25, 0, (C.c_float * 5)(0, 0, 0, 0, 0))
+    oi = intr(oracle_mod, o)
+    aligned, _ = oracle_mod.align_depth_to_other(depth, scale, w, h, intr(oracle_mod, d), oi, extr(oracle_mod, e))
+    assert (aligned > 1).mean() > 0.5
     frames = []
     for rgb in rgbs:
         gray = oracle_mod.rgb_to_grayscale(rgb)
         ref = oracle_mod.extract_frame(gray, oracle_mod.make_config(w, h, levels=1))
-        pos, pts, d32, _ = oracle_mod.keypoint_pixel_to_point(depth, intr, ref["pos"], ref["score"], ref["desc32"], 0)
+        pos, pts, d32, _ = oracle_mod.keypoint_pixel_to_point(aligned, oi, ref["pos"], ref["score"], ref["desc32"], 0)
         frames.append((pos, pts, d32))
     (ppos, ppts, pd32), (cpos, cpts, cd32) = frames
     assert (nprev, ncurr) == (len(ppos), len(cpos))
-    pos_tmp = oracle_mod.reproject_points(ppts, np.eye(4), intr)
+    pos_tmp = oracle_mod.reproject_points(ppts, np.eye(4), oi)
     ridx, rn = oracle_mod.match_keypoints(pos_tmp, pd32, cpos, cd32, 2, 4)
     rkx, rky, rpm, rcm = oracle_mod.match_compact(ridx, cpos, ppts, cpts)
     assert n == rn == len(rkx) and n > 20

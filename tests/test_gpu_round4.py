@@ -1,0 +1,356 @@
+"""Round-4 GPU parity tests (HIP through the C ABI vs the CPU oracle, bit for bit):
+  * f2, the producing half: orbfe_align_depth_to_other / orbfe_align_depth_batch (cuda-align.cu:121-188, :224-280,
+    :366-399) at 848x480 and 1280x720, identity and D4xx-like rigs, distortion polynomials, holes, rectangles that
+    leave the frame, scattered tiles (no LDS window), the launch-grid quirk, both output protocols; its output fed
+    to orbfe_keypoint_pixel_to_point;
+  * f3: a HIP-extracted, HIP-matched frame pair through orbfe_match_compact -> the viewer message
+    (orbfe_wire_frame_encode, WebSocketCom.cpp:163-184), every decoded field against the same chain on the oracle's records;
+  * f4: the matched double3 lists (HIP) through orbfe_best_fit_transform / orbfe_icp (buildStream.cpp:29-188).
+The oracle is unpinned by the reference (it holds no tests); see oracle/orbfe_oracle.h."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from orbfe import synth
+from test_align_oracle import extr, intr
+from test_gpu_parity import dev, stream
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------ f2: align_depth_to_other
+def _align_stage(torch, orbfe, depth, scale, iw, ih, d, o, e, before=None):
+    oh, ow = o[1], o[0]
+    d_depth = dev(torch, depth.view(np.int16))
+    init = np.full((oh, ow), 0x5A5A5A5A, np.uint32) if before is None else before
+    d_out = dev(torch, init.view(np.int32))
+    orbfe.check(orbfe.lib().orbfe_align_depth_to_other(d_out.data_ptr(), d_depth.data_ptr(), None, scale, iw, ih,
+                                                       C.byref(intr(orbfe, d)), C.byref(intr(orbfe, o)),
+                                                       C.byref(extr(orbfe, e)), stream(torch)))
+    torch.cuda.synchronize()
+    return d_out.cpu().numpy().view(np.uint32)
+
+
+def _align_ref(oracle_mod, depth, scale, iw, ih, d, o, e, before=None):
+    out, _ = oracle_mod.align_depth_to_other(depth, scale, iw, ih, intr(oracle_mod, d), intr(oracle_mod, o),
+                                             extr(oracle_mod, e), out_init=before)
+    return out
+
+
+@pytest.mark.parametrize("literal", [False, True])
+@pytest.mark.parametrize("kind", ["identity", "d435", "distorted", "wild"])
+@pytest.mark.parametrize("size", [(848, 480, 848, 480), (1280, 720, 1280, 720), (101, 67, 80, 60), (64, 48, 131, 77),
+                                  (424, 240, 848, 480)])
+def test_align_depth_stage(gpu, oracle_mod, monkeypatch, size, kind, literal):
+    """The stage entry against the oracle's four literal launches.  `literal` forces the reset-to-max / atomicMin /
+    reset-to-zero protocol (ORBFE_ALIGN_LITERAL); the default is the zero-init protocol.  'wild' scatters a tile's
+    rectangles over hundreds of pixels, so its tiles take the straight-to-memory path; (101, 67) rows are not
+    8-byte aligned (scalar loads); 424x240 -> 848x480 makes every rectangle 2-3 pixels wide."""
+    torch, orbfe = gpu
+    if literal:
+        monkeypatch.setenv("ORBFE_ALIGN_LITERAL", "1")
+    dw, dh, ow, oh = size
+    d, o, e, scale = synth.rig(kind, dw, dh, ow, oh)
+    depth = synth.depth_frame(dw, dh, index=dw + len(kind))
+    iw, ih = max(dw, ow), max(dh, oh)
+    got = _align_stage(torch, orbfe, depth, scale, iw, ih, d, o, e)
+    want = _align_ref(oracle_mod, depth, scale, iw, ih, d, o, e)
+    np.testing.assert_array_equal(got, want)
+    if kind != "wild":
+        assert (want != 0).mean() > 0.3
+    else:
+        assert 0.02 < (want != 0).mean() < 0.95
+
+
+def test_align_depth_grid_smaller_than_the_images(gpu, oracle_mod):
+    """image_width / image_height make the launch grid (cuda-align.cu:378-380); the intrinsics bound the kernels.
+    Output pixels beyond the grid keep min(what the buffer held, splats): the literal protocol, whatever the default."""
+    torch, orbfe = gpu
+    dw, dh = 200, 120
+    d, o, e, scale = synth.rig("d435", dw, dh)
+    depth = synth.depth_frame(dw, dh, 9, n_rects=8, holes=0.05)
+    before = np.full((dh, dw), 77777, np.uint32)
+    before[::2] = 3
+    for iw, ih in ((90, 50), (200, 50), (33, 120)):
+        got = _align_stage(torch, orbfe, depth, scale, iw, ih, d, o, e, before)
+        want = _align_ref(oracle_mod, depth, scale, iw, ih, d, o, e, before)
+        np.testing.assert_array_equal(got, want)
+        assert (want == 77777).any() and (want == 3).any()
+
+
+def test_align_depth_zero_z_and_saturating_conversion(gpu, oracle_mod):
+    """other_point z == 0 gives inf / NaN pixels; the float -> int conversion saturates and maps NaN to 0 on both
+    sides (cvt.rzi.s32.f32 in the reference, v_cvt_i32_f32 here, spelled out in the oracle)."""
+    torch, orbfe = gpu
+    w, h = 64, 32
+    rng = np.random.default_rng(1)
+    depth = rng.choice(np.array([0, 512, 1024, 2048], np.uint16), (h, w))
+    k = (w, h, 0.0, 0.0, 1.0, 1.0, 0, (0,) * 5)
+    e = ((1, 0, 0, 0, 1, 0, 0, 0, 1), (0, 0, -1.0))
+    got = _align_stage(torch, orbfe, depth, 2.0 ** -10, w, h, k, k, e)
+    want = _align_ref(oracle_mod, depth, 2.0 ** -10, w, h, k, k, e)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_align_depth_rejects_what_the_reference_cannot_run(gpu):
+    torch, orbfe = gpu
+    d, o, e, scale = synth.rig("identity", 32, 32)
+    buf = torch.zeros(32 * 32, dtype=torch.int32, device="cuda")
+    L = orbfe.lib()
+    for dm, om in [(1, 0), (3, 0), (0, 3)]:
+        dd, oo = list(d), list(o)
+        dd[6], oo[6] = dm, om
+        rc = L.orbfe_align_depth_to_other(buf.data_ptr(), buf.data_ptr(), None, scale, 32, 32, C.byref(intr(orbfe, dd)),
+                                          C.byref(intr(orbfe, oo)), C.byref(extr(orbfe, e)), stream(torch))
+        assert rc == orbfe.ERR_UNSUPPORTED
+    rc = L.orbfe_align_depth_to_other(buf.data_ptr(), buf.data_ptr(), None, float("nan"), 32, 32, C.byref(intr(orbfe, d)),
+                                      C.byref(intr(orbfe, o)), C.byref(extr(orbfe, e)), stream(torch))
+    assert rc == orbfe.ERR_INVALID_ARG
+    rc = L.orbfe_align_depth_to_other(None, buf.data_ptr(), None, scale, 32, 32, C.byref(intr(orbfe, d)),
+                                      C.byref(intr(orbfe, o)), C.byref(extr(orbfe, e)), stream(torch))
+    assert rc == orbfe.ERR_INVALID_ARG
+
+
+@pytest.mark.parametrize("kind,size,n,chunk,pad", [("d435", (848, 480, 848, 480), 19, None, 0),
+                                                  ("d435", (848, 480, 848, 480), 19, 5, 52),
+                                                  ("distorted", (1280, 720, 1280, 720), 9, None, 8),
+                                                  ("wild", (424, 240, 424, 240), 11, 3, 0),
+                                                  ("d435", (101, 67, 80, 60), 10, None, 3),
+                                                  ("identity", (640, 480, 640, 480), 3, None, 0)])
+def test_align_depth_batch(gpu, oracle_mod, monkeypatch, kind, size, n, chunk, pad):
+    """n frames per call (one frame per XCD, 8 to a grid row; fewer than 8 the plain grid), padded frame strides,
+    several launches per call (ORBFE_ALIGN_CHUNK): every frame equals the oracle's, the padding is untouched."""
+    torch, orbfe = gpu
+    if chunk:
+        monkeypatch.setenv("ORBFE_ALIGN_CHUNK", str(chunk))
+    dw, dh, ow, oh = size
+    d, o, e, scale = synth.rig(kind, dw, dh, ow, oh)
+    frames = synth.depth_frames(dw, dh, n, first_index=40)
+    in_stride, out_stride = dw * dh + pad, ow * oh + 4 * pad
+    src = np.full((n, in_stride), 0x7777, np.uint16)
+    src[:, :dw * dh] = frames.reshape(n, -1)
+    d_src = dev(torch, src.view(np.int16))
+    d_out = torch.full((n, out_stride), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+    orbfe.check(orbfe.lib().orbfe_align_depth_batch(d_out.data_ptr(), out_stride, d_src.data_ptr(), in_stride, n, scale,
+                                                    C.byref(intr(orbfe, d)), C.byref(intr(orbfe, o)),
+                                                    C.byref(extr(orbfe, e)), stream(torch)))
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy().view(np.uint32)
+    for f in range(n):
+        want = _align_ref(oracle_mod, frames[f], scale, max(dw, ow), max(dh, oh), d, o, e)
+        np.testing.assert_array_equal(got[f, :ow * oh].reshape(oh, ow), want, err_msg="frame %d" % f)
+    assert (got[:, ow * oh:] == 0x5A5A5A5A).all()
+
+
+def test_align_depth_feeds_keypoint_pixel_to_point(gpu, oracle_mod):
+    """buildStream.cpp:385 -> :468: the aligned image the HIP kernel wrote is what orbfe_keypoint_pixel_to_point reads;
+    the compacted keypoints and their 3-D points must equal the oracle's chain."""
+    torch, orbfe = gpu
+    w, h, n = 848, 480, 405
+    d, o, e, scale = synth.rig("d435", w, h)
+    depth = synth.depth_frame(w, h, 21)
+    d_depth = dev(torch, depth.view(np.int16))
+    d_al = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    L = orbfe.lib()
+    orbfe.check(L.orbfe_align_depth_to_other(d_al.data_ptr(), d_depth.data_ptr(), None, scale, w, h, C.byref(intr(orbfe, d)),
+                                             C.byref(intr(orbfe, o)), C.byref(extr(orbfe, e)), stream(torch)))
+    rng = np.random.default_rng(8)
+    pos = np.stack([rng.integers(0, w, n), rng.integers(0, h, n)], 1).astype(np.float32)
+    score = rng.choice([0.0, 2.0, 57.0], n).astype(np.float32)
+    desc = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+    o_pos = torch.zeros((n, 2), device="cuda")
+    o_pts = torch.zeros((n, 3), dtype=torch.float64, device="cuda")
+    o_desc = torch.zeros(n, dtype=torch.int32, device="cuda")
+    o_n = torch.zeros(1, dtype=torch.int32, device="cuda")
+    d_pos, d_score, d_desc = dev(torch, pos), dev(torch, score), dev(torch, desc.view(np.int32))
+    for fix in (0, 1):
+        orbfe.check(L.orbfe_keypoint_pixel_to_point(d_al.data_ptr(), C.byref(intr(orbfe, o)), w, h, o_pos.data_ptr(),
+                                                    d_pos.data_ptr(), d_score.data_ptr(), o_pts.data_ptr(), o_desc.data_ptr(),
+                                                    d_desc.data_ptr(), n, o_n.data_ptr(), fix, stream(torch)))
+        cnt = int(o_n.cpu()[0])
+        aligned = _align_ref(oracle_mod, depth, scale, w, h, d, o, e)
+        rpos, rpts, rdesc, rcnt = oracle_mod.keypoint_pixel_to_point(aligned, intr(oracle_mod, o), pos, score, desc, fix)
+        assert cnt == rcnt and 50 < cnt < n
+        np.testing.assert_array_equal(o_pos.cpu().numpy()[:cnt], rpos)
+        np.testing.assert_array_equal(o_pts.cpu().numpy()[:cnt].view(np.uint64), rpts.view(np.uint64))
+        np.testing.assert_array_equal(o_desc.cpu().numpy()[:cnt].view(np.uint32), rdesc)
+
+
+def test_align_depth_is_graph_capturable_and_repeatable(gpu, oracle_mod):
+    """Nothing in the call allocates, synchronises or reads device memory on the host: it records into a graph, and
+    replays give the same bytes (the atomics are order-free)."""
+    torch, orbfe = gpu
+    w, h, n = 424, 240, 9
+    d, o, e, scale = synth.rig("d435", w, h)
+    frames = synth.depth_frames(w, h, n, first_index=70)
+    d_src = dev(torch, frames.view(np.int16))
+    d_out = torch.zeros((n, h * w), dtype=torch.int32, device="cuda")
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    args = (d_out.data_ptr(), w * h, d_src.data_ptr(), w * h, n, scale, C.byref(intr(orbfe, d)), C.byref(intr(orbfe, o)),
+            C.byref(extr(orbfe, e)))
+    with torch.cuda.stream(s):
+        orbfe.check(orbfe.lib().orbfe_align_depth_batch(*args, s.cuda_stream))  # warm-up outside the capture
+        s.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            orbfe.check(orbfe.lib().orbfe_align_depth_batch(*args, torch.cuda.current_stream().cuda_stream))
+    first = None
+    for _ in range(3):
+        d_out.fill_(-1)
+        g.replay()
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy().view(np.uint32).copy()
+        if first is None:
+            first = got
+        assert (got == first).all()
+    for f in (0, n - 1):
+        np.testing.assert_array_equal(first[f].reshape(h, w), _align_ref(oracle_mod, frames[f], scale, w, h, d, o, e))
+
+
+# ------------------------------------------------------------------ f3 / f4 on HIP-produced data
+def _pair_through_the_reference_chain(torch, orbfe, oracle_mod, w, h, seed):
+    """Two frames (the second shifted by one pixel) through the HIP stage calls the reference issues per frame
+    (buildStream.cpp:385-481: align, extract, keypoint_pixel_to_point), then reproject + match + compact (:545-556,
+    post_processing.cu:234-341) -- and the same chain on the oracle.  Returns both sides' results."""
+    L = orbfe.lib()
+    a, b = synth.shifted_pair(w, h, seed, dx=1, dy=0, **synth.DENSE)
+    d, o, e, scale = synth.rig("d435", w, h)
+    depth = synth.depth_frame(w, h, seed, holes=0.1)
+    gi, oi = intr(orbfe, o), intr(oracle_mod, o)
+    aligned_ref = _align_ref(oracle_mod, depth, scale, w, h, d, o, e)
+    d_depth = dev(torch, depth.view(np.int16))
+    d_al = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    orbfe.check(L.orbfe_align_depth_to_other(d_al.data_ptr(), d_depth.data_ptr(), None, scale, w, h, C.byref(intr(orbfe, d)),
+                                             C.byref(gi), C.byref(extr(orbfe, e)), stream(torch)))
+    ctx = orbfe.Context(w, h, levels=1, max_batch=2)
+    K = ctx.K
+    frames = np.stack([a, b])
+    d_in = dev(torch, frames)
+    rec = torch.zeros(2 * ctx.cap * 52, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(2, dtype=torch.int32, device="cuda")
+    soa_t = dict(pos=torch.zeros((2, K, 2), device="cuda"), score=torch.zeros((2, K), device="cuda"),
+                 level=torch.zeros((2, K), dtype=torch.int32, device="cuda"), angle=torch.zeros((2, K), device="cuda"),
+                 desc=torch.zeros((2, K, 32), dtype=torch.uint8, device="cuda"),
+                 d32=torch.zeros((2, K), dtype=torch.int32, device="cuda"))
+    soa = orbfe.Soa(soa_t["pos"].data_ptr(), soa_t["score"].data_ptr(), soa_t["level"].data_ptr(),
+                    soa_t["angle"].data_ptr(), soa_t["desc"].data_ptr(), soa_t["d32"].data_ptr())
+    ctx.extract(d_in.data_ptr(), w, w * h, 2, rec.data_ptr(), cnt.data_ptr(), soa, stream(torch))
+    gpu_side, ref_side = [], []
+    for f in range(2):
+        o_pos = torch.zeros((K, 2), device="cuda")
+        o_pts = torch.zeros((K, 3), dtype=torch.float64, device="cuda")
+        o_d32 = torch.zeros(K, dtype=torch.int32, device="cuda")
+        o_n = torch.zeros(1, dtype=torch.int32, device="cuda")
+        orbfe.check(L.orbfe_keypoint_pixel_to_point(d_al.data_ptr(), C.byref(gi), w, h, o_pos.data_ptr(),
+                                                    soa_t["pos"][f].data_ptr(), soa_t["score"][f].data_ptr(),
+                                                    o_pts.data_ptr(), o_d32.data_ptr(), soa_t["d32"][f].data_ptr(), K,
+                                                    o_n.data_ptr(), 0, stream(torch)))
+        gpu_side.append((o_pos, o_pts, o_d32, int(o_n.cpu()[0])))
+        ref = oracle_mod.extract_frame(frames[f], oracle_mod.make_config(w, h, levels=1))
+        ref_side.append(oracle_mod.keypoint_pixel_to_point(aligned_ref, oi, ref["pos"], ref["score"], ref["desc32"], 0))
+    (ppos, ppts, pd32, np_), (cpos, cpts, cd32, nc) = gpu_side
+    assert (np_, nc) == (ref_side[0][3], ref_side[1][3]) and np_ > 100
+    T = np.eye(4)
+    Tc = (C.c_double * 16)(*T.T.reshape(-1))
+    pos_tmp = torch.zeros((K, 2), device="cuda")
+    orbfe.check(L.orbfe_reproject_points(pos_tmp.data_ptr(), ppts.data_ptr(), np_, Tc, C.byref(gi), stream(torch)))
+    midx = torch.zeros(K, dtype=torch.int32, device="cuda")
+    mnum = torch.zeros(1, dtype=torch.int32, device="cuda")
+    orbfe.check(L.orbfe_match_keypoints(pos_tmp.data_ptr(), pd32.data_ptr(), np_, cpos.data_ptr(), cd32.data_ptr(), nc, 2, 4,
+                                        midx.data_ptr(), mnum.data_ptr(), stream(torch)))
+    kx = torch.zeros(K, dtype=torch.int16, device="cuda")
+    ky = torch.zeros(K, dtype=torch.int16, device="cuda")
+    pm = torch.zeros((K, 3), dtype=torch.float64, device="cuda")
+    cm = torch.zeros((K, 3), dtype=torch.float64, device="cuda")
+    orbfe.check(L.orbfe_match_compact(midx.data_ptr(), np_, ppts.data_ptr(), cpts.data_ptr(), cpos.data_ptr(), pm.data_ptr(),
+                                      cm.data_ptr(), kx.data_ptr(), ky.data_ptr(), mnum.data_ptr(), stream(torch)))
+    torch.cuda.synchronize()
+    m = int(mnum.cpu()[0])
+    got = dict(n=m, kx=kx.cpu().numpy().view(np.uint16)[:m].copy(), ky=ky.cpu().numpy().view(np.uint16)[:m].copy(),
+               prev=pm.cpu().numpy()[:m].copy(), curr=cm.cpu().numpy()[:m].copy())
+    rppos, rppts, rpd32, _ = ref_side[0]
+    rcpos, rcpts, rcd32, _ = ref_side[1]
+    rtmp = oracle_mod.reproject_points(rppts, T, oi)
+    ridx, rn = oracle_mod.match_keypoints(rtmp, rpd32, rcpos, rcd32, 2, 4)
+    rkx, rky, rpm, rcm = oracle_mod.match_compact(ridx, rcpos, rppts, rcpts)
+    want = dict(n=rn, kx=rkx, ky=rky, prev=rpm, curr=rcm)
+    ctx.close()
+    return got, want, a
+
+
+def test_f3_hip_frame_pair_through_the_viewer_message(gpu, oracle_mod):
+    """align -> extract -> keypoint_pixel_to_point -> reproject -> match_keypoints -> match_compact on HIP, the
+    matched current keypoints (slam_frame_t::keypoints_x / _y, types.h:29-30) into orbfe_wire_frame_encode
+    (WebSocketCom.cpp:163-184), decoded: every field equals the same chain run on the oracle's records."""
+    torch, orbfe = gpu
+    from test_wire import decode
+    L = orbfe.lib()
+    w, h = 848, 480
+    got, want, image = _pair_through_the_reference_chain(torch, orbfe, oracle_mod, w, h, 91)
+    assert got["n"] == want["n"] and got["n"] > 30
+    docs = []
+    theta = (0.12, -0.4, 1.9)
+    for side in (got, want):
+        kx, ky = np.ascontiguousarray(side["kx"]), np.ascontiguousarray(side["ky"])
+        m = orbfe.FrameMessage((C.c_float * 3)(*theta), w, h, 1, kx.ctypes.data, ky.ctypes.data, int(side["n"]),
+                               image.ctypes.data, image.size)
+        need = L.orbfe_wire_frame_size(C.byref(m))
+        buf = (C.c_uint8 * need)()
+        assert L.orbfe_wire_frame_encode(C.byref(m), buf, need, None) == 0
+        docs.append(bytes(buf))
+    assert docs[0] == docs[1]
+    fields = {k: v for k, _, v in decode(docs[0])}
+    assert np.frombuffer(fields["keypoints_x"], np.uint16).tolist() == want["kx"].tolist()
+    assert np.frombuffer(fields["keypoints_y"], np.uint16).tolist() == want["ky"].tolist()
+    assert (fields["width"], fields["height"], fields["channels"]) == (w, h, 1)
+    assert fields["image"] == image.tobytes()
+    ang = (C.c_int32 * 3)()
+    L.orbfe_wire_angles((C.c_float * 3)(*theta), ang)
+    assert (fields["ax"], fields["ay"], fields["az"]) == tuple(ang)
+
+
+def test_f4_pose_from_hip_matches(gpu, oracle_mod):
+    """The matched double3 lists the HIP chain produced (bit-equal to the oracle's) through orbfe_best_fit_transform
+    and orbfe_icp (buildStream.cpp:29-188): equal to the numpy restatement on the oracle's lists within 1e-9 (Eigen's
+    JacobiSVD bits are not reproducible here: DESIGN.md 6b), and a known rigid motion applied to the matched current
+    points is recovered."""
+    torch, orbfe = gpu
+    import oracle_pose
+    L = orbfe.lib()
+    got, want, _ = _pair_through_the_reference_chain(torch, orbfe, oracle_mod, 848, 480, 92)
+    n = got["n"]
+    assert n == want["n"] and n > 30
+    np.testing.assert_array_equal(got["prev"].view(np.uint64), want["prev"].view(np.uint64))
+    np.testing.assert_array_equal(got["curr"].view(np.uint64), want["curr"].view(np.uint64))
+    A = np.ascontiguousarray(got["prev"])
+    ang = np.radians(3.0)
+    R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    t = np.array([12.5, -3.0, 40.0])
+    B = np.ascontiguousarray(got["curr"] @ R.T + t)
+    T = (C.c_double * 16)()
+    assert L.orbfe_best_fit_transform(A.ctypes.data, B.ctypes.data, n, T) == 0
+    Tn = np.array(T).reshape(4, 4).T
+    ref = oracle_pose.best_fit_transform(want["prev"], want["curr"] @ R.T + t)
+    np.testing.assert_allclose(Tn, ref, rtol=0, atol=1e-9 * max(1.0, np.abs(ref).max()))
+    # prev and curr are the same scene points up to the one-pixel shift's depth lookup: the fit is R, t up to that noise
+    resid = np.linalg.norm(A @ Tn[:3, :3].T + Tn[:3, 3] - B, axis=1)
+    assert np.median(resid) < 60.0
+    # exact recovery on noise-free input: B2 = R A + t
+    B2 = np.ascontiguousarray(A @ R.T + t)
+    assert L.orbfe_best_fit_transform(A.ctypes.data, B2.ctypes.data, n, T) == 0
+    T2 = np.array(T).reshape(4, 4).T
+    np.testing.assert_allclose(T2[:3, :3], R, atol=1e-9)
+    np.testing.assert_allclose(T2[:3, 3], t, atol=1e-6)
+    # the ICP loop (the reference's only call is commented out, :572) on the same lists, in units where its
+    # "farther than 100 pairs with target 0" rule (:103-121) does not decide everything: decimetres, a small motion
+    As = np.ascontiguousarray(A / 100.0)
+    a1 = np.radians(0.5)
+    R1 = np.array([[np.cos(a1), -np.sin(a1), 0], [np.sin(a1), np.cos(a1), 0], [0, 0, 1]])
+    Bs = np.ascontiguousarray((As @ R1.T + [0.02, -0.01, 0.03])[np.random.default_rng(4).permutation(n)])
+    assert L.orbfe_icp(As.ctypes.data, Bs.ctypes.data, n, 20, 0, T) == 0
+    Ti = np.array(T).reshape(4, 4).T
+    refi = oracle_pose.icp(As, Bs, 20, 0)
+    np.testing.assert_allclose(Ti, refi, rtol=0, atol=1e-8 * max(1.0, np.abs(refi).max()))
+    np.testing.assert_allclose(Ti[:3, :3], R1, atol=1e-3)

@@ -10,11 +10,12 @@ mkdir -p $OUT
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function"
 /opt/rocm/bin/hipcc $F "$@" -c -o $OUT/stage.o $SRC/stage_kernels.hip &
 /opt/rocm/bin/hipcc $F "$@" -c -o $OUT/batch.o $SRC/batch_kernels.hip &
+/opt/rocm/bin/hipcc $F "$@" -c -o $OUT/align.o $SRC/align_depth.hip &
 /opt/rocm/bin/hipcc $F -fno-honor-nans -mllvm -amdgpu-mfma-vgpr-form "$@" -c -o $OUT/mfma.o $SRC/match_mfma.hip &
 /opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC -ffp-contract=off -c -o $OUT/wire.o $SRC/wire_bson.cpp &
 /opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC -ffp-contract=off -c -o $OUT/pose.o $SRC/pose_host.cpp &
 (g++ -O2 -std=c++17 -ffp-contract=off -o $OUT/gen_steer_table $SRC/gen_steer_table.cpp && $OUT/gen_steer_table $OUT/steer_events.inc 2>/dev/null && /opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC -ffp-contract=off -I$OUT "$@" -c -o $OUT/steer.o $SRC/steer_table.cpp) &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/liborbfe.so $OUT/stage.o $OUT/batch.o $OUT/mfma.o $OUT/wire.o $OUT/pose.o $OUT/steer.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/liborbfe.so $OUT/stage.o $OUT/batch.o $OUT/align.o $OUT/mfma.o $OUT/wire.o $OUT/pose.o $OUT/steer.o
 rm -f $OUT/*.o $OUT/gen_steer_table $OUT/steer_events.inc
 echo $OUT/liborbfe.so

@@ -25,6 +25,7 @@ STAGES = {
     "pyramid": ["pyramid_fused_kernel", "blur_batch_kernel", "halfsample_batch_kernel"],
     "detect": ["detect_tile_kernel"],
     "describe": ["select_kernel", "describe_tile_kernel", "describe_kernel"],
+    "align": ["align_fill_kernel", "align_splat_kernel", "align_unmax_kernel"],
     "match": ["match_gather_kernel", "match_batch_256_kernel", "match_batch_ref_kernel", "match_expand_kernel",
               "match_mfma_kernel", "match_bucket_kernel", "match_window_kernel"],
 }
@@ -54,7 +55,9 @@ except Exception:
 act = {s: sum(per_launch(q, p, lambda v: v.get("SQ_ACTIVE_INST_VALU", {}).get("avg", 0.0)) for p in ks) for s, ks in STAGES.items()}
 cyc = {s: sum(per_launch(q, p, lambda v: v.get("GRBM_GUI_ACTIVE", {}).get("avg", 0.0)) for p in ks) / 8.0 for s, ks in STAGES.items()}
 stages["valu_wave_instructions"] = valu
-stages["valu_pipe_busy"] = {s: (act[s] * 4.0 / 1024.0 / cyc[s] if cyc[s] else None) for s in STAGES}
+# (an ISSUE COUNT, not a busy fraction: the counter charges every vector instruction a quad-cycle, full-rate instructions
+# retire in 2.76 cycles here, so detect reads 1.06)
+stages["valu_issue_quad_cycles_per_simd_cycle"] = {s: (act[s] * 4.0 / 1024.0 / cyc[s] if cyc[s] else None) for s in STAGES}
 for name, counter in (("lds_bank_conflict_cycles", "SQ_LDS_BANK_CONFLICT"), ("salu_wave_instructions", "SQ_INSTS_SALU"),
                       ("lds_wave_instructions", "SQ_INSTS_LDS"), ("mfma_wave_instructions", "SQ_INSTS_MFMA")):
     stages[name] = {s: sum(per_launch(q, p, lambda v: v.get(counter, {}).get("avg", 0.0)) for p in ks) for s, ks in STAGES.items()}
@@ -63,7 +66,7 @@ stages["batch"] = batch
 stages["csrc_sha256"] = orbfe.source_hash()
 allj[mode] = stages
 allj["_note"] = ("per stage launch (`batch` frames): HBM-side bytes from rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE "
-                 "passes (reads doubled per the gfx950 correction), VALU wave-instructions (SQ_INSTS_VALU) and the fraction of "
-                 "SIMD cycles with a VALU instruction executing (SQ_ACTIVE_INST_VALU x 4 / 1024 / cycles) from SQ passes")
+                 "passes (reads doubled per the gfx950 correction), VALU wave-instructions (SQ_INSTS_VALU) and the vector-instruction "
+                 "issue quad-cycles per SIMD-cycle (SQ_ACTIVE_INST_VALU x 4 / 1024 / cycles; not a fraction) from SQ passes")
 json.dump(allj, open(out, "w"), indent=1, sort_keys=True)
 print(json.dumps(stages))
