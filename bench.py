@@ -380,7 +380,7 @@ def align_bench(args, torch, np, orbfe, dev, json_out):
            "dtype": "f32 (projection arithmetic) / u16 -> u32 (depth)", "data": "synthetic",
            "config": {"workload": "align_depth_to_other over %d depth frames 848x480 per call, D435-like rig (depth 87 deg, colour 69 deg, "
                                   "15 mm baseline), 15 %% holes" % B, "mode": "align", "frames_per_gpu_per_step": B,
-                      "distinct_frames_per_rank": n_distinct, "frames_per_launch": int(os.environ.get("ORBFE_ALIGN_CHUNK", "64")),
+                      "distinct_frames_per_rank": n_distinct, "frames_per_launch": int(os.environ.get("ORBFE_ALIGN_CHUNK", "128")),
                       "output_pixels_covered": covered},
            "pixels_per_s": B * w * h * args.steps / elapsed,
            "roofline": {"bound": "hbm", "achieved": ab / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

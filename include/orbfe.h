@@ -217,8 +217,9 @@ int orbfe_align_depth_batch(uint32_t *d_aligned_out, size_t out_frame_stride, co
 /* kernel_reproject_prev_points, src/cuda/post_processing.cu:72-90 (with project_point_to_pixel_double,
  * :11-43): the prev frame's 3-D points moved by T_w2c_prev_curr (HOST pointer to 16 doubles,
  * column-major as Eigen::Matrix4d) and projected to pixels -- the positions orbfe_match_keypoints takes
- * as d_pos_prev.  Models 0 (none) and 1 (modified Brown-Conrady) as in the reference; 2 and 3
- * (it asserts / never uses them): ORBFE_ERR_UNSUPPORTED.  Parity unpinned at the ulp level (Eigen's
+ * as d_pos_prev.  Model 1 (modified Brown-Conrady) applies its polynomial; 0, 2 and 4 project
+ * without distortion, exactly as the reference (its assert against model 2 is commented out, :15, and a D4xx colour
+ * stream reports model 2); 3 (f-theta: libdevice's double atan / tan) returns ORBFE_ERR_UNSUPPORTED.  Parity unpinned at the ulp level (Eigen's
  * product order and nvcc's FMA contraction are not observable): ((T_i0 x + T_i1 y) + T_i2 z) + T_i3. */
 int orbfe_reproject_points(float *d_pos_out, const double *d_points_prev, int keypoints_num_prev,
                            const double *T_w2c_prev_curr, const orbfe_intrinsics *intrin, orbfe_stream_t stream);

@@ -34,6 +34,11 @@ namespace orbfe {
 constexpr int kAlignTileW = 64, kAlignTileH = 16; // depth pixels per workgroup: 256 threads x 4 pixels of one row
 constexpr int kAlignWin = 6144;                    // LDS window, u32 entries (24 KB: six workgroups per CU)
 constexpr uint32_t kAlignMax = 9999999u;           // the reference's sentinel (:265, :277)
+// Profiling aid (tools/build_variant.sh): -DORBFE_ALIGN_ABLATE=1 drops the window flush (no global atomics), 2 also the
+// LDS splat, 3 also the projection arithmetic.  Results are then WRONG; the builds exist to attribute time to phases.
+#ifndef ORBFE_ALIGN_ABLATE
+#define ORBFE_ALIGN_ABLATE 0
+#endif
 
 struct AlignArgs {
     orbfe_intrinsics d, o;
@@ -44,14 +49,26 @@ struct AlignArgs {
     int tiles_x, tiles_y;     // ceil(mx / 64), ceil(my / 16)
     int n_frames, grid8;      // frames of this launch; 1: (8 * items, ceil(n / 8)) grid, blockIdx.x & 7 = frame in its row
     size_t in_stride, out_stride; // elements (u16 / u32) between frames
+    // pipelined launches (whole, 16-byte aligned outputs): this launch also CLEARS the next chunk's frames (n_fill of them,
+    // fill_value) and CLOSES the previous chunk's (n_close: 9999999 -> 0) -- two memory-bound passes carried by workgroups
+    // interleaved with the VALU-bound splat workgroups instead of two launches of their own in between
+    int n_slots;                  // max(n_frames, n_fill, n_close): frame slots of the grid
+    int mem_items;                // memory work items per frame (kAlignMemQuads 16-byte quads each); 0: no memory roles
+    int mem_total;                // memory items per frame slot: mem_items (fill only) or 2 * mem_items (fill, then close)
+    int items_total;              // per frame slot: tiles + mem_total
+    int n_fill, n_close;
+    uint32_t fill_value;
+    long long fill_off, close_off; // first frame of the next / previous chunk, in elements from `out`
+    int quads;                    // 16-byte quads per output frame
 };
+constexpr int kAlignMemQuads = 1024; // 16 KB of output per memory work item
 
 __device__ inline bool align_frame_item(const AlignArgs &A, int *frame, int *item)
 {
     if (A.grid8) {
         *frame = blockIdx.y * 8 + (blockIdx.x & 7);
         *item = blockIdx.x >> 3;
-        return *frame < A.n_frames;
+        return *frame < A.n_slots;
     }
     *frame = blockIdx.y;
     *item = blockIdx.x;
@@ -65,10 +82,42 @@ __device__ inline int cvt_rz_sat(float f)
     return r;
 }
 
+// x / z and y / z, correctly rounded, with ONE reciprocal.  hipcc expands an IEEE float division into v_div_scale x 2,
+// v_rcp, 2 fma (the reciprocal's Newton step), v_mul, 3 fma, v_div_fmas, v_div_fixup: 12 instructions, 24 for the two
+// quotients of a projection.  When v_div_scale leaves its operands alone the scaling flag is clear, v_div_fmas is a plain
+// fma, v_div_fixup returns the quotient as it is, and the two reciprocals are the same number: the sequence below IS
+// hipcc's instruction for instruction (same operations, same order, hence the same bits), 13 instead of 24.  v_div_scale
+// is the identity when both operands are non-zero normals, |exponent difference| < 96, 1 / z and x / z are normals and x is
+// not tiny (biased exponent > 23) -- all implied by 2^-40 <= |x|, |y|, |z| <= 2^40, the guard the caller tests (any lane
+// of the wave outside it: the whole wave takes the plain `/`).  tests/test_gpu_round4.py compares both paths bit for bit.
+__device__ inline void div2_in_range(float x, float y, float z, float *qx, float *qy)
+{
+    const float r0 = __builtin_amdgcn_rcpf(z);
+    const float e = __builtin_fmaf(-z, r0, 1.0f);
+    const float r = __builtin_fmaf(e, r0, r0);
+    float m = x * r;
+    float f = __builtin_fmaf(-z, m, x);
+    m = __builtin_fmaf(f, r, m);
+    f = __builtin_fmaf(-z, m, x);
+    *qx = __builtin_fmaf(f, r, m);
+    m = y * r;
+    f = __builtin_fmaf(-z, m, y);
+    m = __builtin_fmaf(f, r, m);
+    f = __builtin_fmaf(-z, m, y);
+    *qy = __builtin_fmaf(f, r, m);
+}
+__device__ inline bool div2_guard(float x, float y, float z)
+{
+    // v_min3 / v_max3 on the magnitudes; NaN fails both compares
+    const float lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(x), __builtin_fabsf(y)), __builtin_fabsf(z));
+    const float hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(x), __builtin_fabsf(y)), __builtin_fabsf(z));
+    return lo >= 0x1p-40f && hi <= 0x1p40f;
+}
+
 // kernel_transfer_pixels (:121-161) for one corner whose normalised depth-image coordinates (before the inverse
 // distortion) are (X, Y): deproject (:57-81), transform (:112-119), project (:23-54), round (:154-155)
-template <bool DD, bool DO>
-__device__ inline void map_corner(const AlignArgs &A, float depth_val, float X, float Y, int *px, int *py)
+template <bool DD>
+__device__ inline void to_other_point(const AlignArgs &A, float depth_val, float X, float Y, float q[3])
 {
     ORBFE_NO_CONTRACT
     float x = X, y = Y;
@@ -86,7 +135,6 @@ __device__ inline void map_corner(const AlignArgs &A, float depth_val, float X, 
         y = uy;
     }
     const float p0 = depth_val * x, p1 = depth_val * y, p2 = depth_val;
-    float q[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         float t = A.e.rotation[i] * p0 + A.e.rotation[3 + i] * p1;
@@ -94,8 +142,12 @@ __device__ inline void map_corner(const AlignArgs &A, float depth_val, float X, 
         t = t + A.e.translation[i];
         q[i] = t;
     }
-    x = q[0] / q[2];
-    y = q[1] / q[2];
+}
+// (x, y) = other_point.xy / other_point.z -> the rounded pixel
+template <bool DO>
+__device__ inline void to_other_pixel(const AlignArgs &A, float x, float y, int *px, int *py)
+{
+    ORBFE_NO_CONTRACT
     if (DO) { // RS2_DISTORTION_MODIFIED_BROWN_CONRADY on the other camera
         const float *c = A.o.coeffs;
         const float r2 = x * x + y * y;
@@ -128,24 +180,34 @@ __device__ inline void out_min(uint32_t *p, uint32_t v)
     }
 }
 
-__device__ inline int wave_min_i32(int v)
+// (x, y) pairs as two signed 16-bit lanes of a dword (image sizes are < 32768): component-wise minimum / maximum over the
+// wave in six DPP steps each -- v_pk_min_i16 / v_pk_max_i16 with a DPP operand, no LDS crossbar -- result in every lane
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ inline uint32_t pk_min_i16(uint32_t a, uint32_t b)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const int o = __shfl_xor(v, off);
-        v = o < v ? o : v;
-    }
-    return v;
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
 }
-__device__ inline int wave_max_i32(int v)
+__device__ inline uint32_t pk_max_i16(uint32_t a, uint32_t b)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const int o = __shfl_xor(v, off);
-        v = o > v ? o : v;
-    }
-    return v;
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
 }
+#define ORBFE_WAVE_PK_REDUCE(name, op)                                                                         \
+    __device__ inline uint32_t name(uint32_t v)                                                                \
+    {                                                                                                          \
+        /* lanes with no source keep their own value (old = v, bound_ctrl off): op(v, v) = v */               \
+        v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xF, 0xF, false));             \
+        v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x112, 0xF, 0xF, false));             \
+        v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114, 0xF, 0xF, false));             \
+        v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118, 0xF, 0xF, false));             \
+        v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xA, 0xF, false));             \
+        v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xC, 0xF, false));             \
+        return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);                                               \
+    }
+ORBFE_WAVE_PK_REDUCE(wave_pk_min_i16, pk_min_i16)
+ORBFE_WAVE_PK_REDUCE(wave_pk_max_i16, pk_max_i16)
+__device__ inline uint32_t pk_xy(int x, int y) { return ((uint32_t)x & 0xFFFFu) | ((uint32_t)y << 16); }
+__device__ inline int pk_x(uint32_t v) { return (int)(short)(v & 0xFFFFu); }
+__device__ inline int pk_y(uint32_t v) { return (int)v >> 16; }
 
 // VEC: depth rows are 8-byte aligned at every multiple of 4 pixels (width % 4 == 0, aligned base and frame stride)
 template <bool DD, bool DO, bool ZERO_INIT, bool VEC>
@@ -153,27 +215,56 @@ __global__ void __launch_bounds__(256)
 align_splat_kernel(uint32_t *__restrict__ out, const uint16_t *__restrict__ depth, AlignArgs A)
 {
     ORBFE_NO_CONTRACT
-    __shared__ uint32_t s_win[kAlignWin];
+    // the window (row pitch a multiple of 4 entries, left edge at a multiple of 4 output pixels: 16-byte quads), then
+    // one dump entry per thread: the branch-free splat sends what a rectangle does not cover there
+    __shared__ __attribute__((aligned(16))) uint32_t s_win[kAlignWin + 256];
     __shared__ float s_tx[kAlignTileW + 1], s_ty[kAlignTileH + 1];
-    __shared__ int s_box[4]; // x0, y0 (minima), x1, y1 (maxima)
+    __shared__ uint32_t s_box[2 * 4]; // per wave: (x0, y0) minima, (x1, y1) maxima, packed
 
     int frame, item;
     if (!align_frame_item(A, &frame, &item)) return;
+    const int tid = threadIdx.x;
+    if (A.mem_items) {
+        // this frame slot's items_total work items: memory items spread evenly among the tiles (item j is a memory item
+        // iff the running count floor(j * M / T) steps at j), so that the dispatcher hands every CU a mix of both kinds
+        const uint32_t jm = (uint32_t)item * (uint32_t)A.mem_total;
+        const int before = (int)(jm / (uint32_t)A.items_total);
+        const bool is_mem = jm - (uint32_t)before * (uint32_t)A.items_total + (uint32_t)A.mem_total >= (uint32_t)A.items_total;
+        if (is_mem) { // uniform
+            const bool closing = before >= A.mem_items;
+            const int mi = closing ? before - A.mem_items : before;
+            if (frame >= (closing ? A.n_close : A.n_fill)) return;
+            uint4 *base = reinterpret_cast<uint4 *>(out + (closing ? A.close_off : A.fill_off) + (long long)frame * (long long)A.out_stride);
+#pragma unroll
+            for (int it = 0; it < kAlignMemQuads / 256; it++) {
+                const int q = mi * kAlignMemQuads + it * 256 + tid;
+                if (q >= A.quads) break;
+                if (!closing) {
+                    base[q] = make_uint4(A.fill_value, A.fill_value, A.fill_value, A.fill_value);
+                } else { // kernel_reset_to_zero (:269-280)
+                    uint4 v = base[q];
+                    if (v.x == kAlignMax || v.y == kAlignMax || v.z == kAlignMax || v.w == kAlignMax) {
+                        v.x = v.x == kAlignMax ? 0u : v.x;
+                        v.y = v.y == kAlignMax ? 0u : v.y;
+                        v.z = v.z == kAlignMax ? 0u : v.z;
+                        v.w = v.w == kAlignMax ? 0u : v.w;
+                        base[q] = v;
+                    }
+                }
+            }
+            return;
+        }
+        item -= before;
+    }
+    if (frame >= A.n_frames) return;
     const int ty_t = item / A.tiles_x, tx_t = item - ty_t * A.tiles_x;
     const int X0 = tx_t * kAlignTileW, Y0 = ty_t * kAlignTileH;
-    const int tid = threadIdx.x;
     depth += (size_t)frame * A.in_stride;
     out += (size_t)frame * A.out_stride;
 
     // (pixel -+ 0.5 - pp) / f per column and per row of the tile; entry i is corner -0.5 of pixel i = corner +0.5 of i - 1
     if (tid <= kAlignTileW) s_tx[tid] = (((float)(X0 + tid) + -0.5f) - A.d.ppx) / A.d.fx;
     else if (tid >= 128 && tid <= 128 + kAlignTileH) s_ty[tid - 128] = (((float)(Y0 + tid - 128) + -0.5f) - A.d.ppy) / A.d.fy;
-    if (tid == 0) {
-        s_box[0] = 0x7FFFFFFF;
-        s_box[1] = 0x7FFFFFFF;
-        s_box[2] = -0x7FFFFFFF;
-        s_box[3] = -0x7FFFFFFF;
-    }
 
     // this thread: 4 consecutive pixels of one row
     const int lx = (tid & 15) * 4, ly = tid >> 4;
@@ -197,73 +288,133 @@ align_splat_kernel(uint32_t *__restrict__ out, const uint16_t *__restrict__ dept
     }
     __syncthreads();
 
-    int p0x[4], p0y[4], p1x[4], p1y[4];
-    int bx0 = 0x7FFFFFFF, by0 = 0x7FFFFFFF, bx1 = -0x7FFFFFFF, by1 = -0x7FFFFFFF;
+    // rectangle of pixel k: corner p0 = (x, y) packed, extent (w, h) = p1 - p0; w < 0: nothing to write
+    uint32_t p0[4];
+    int rw[4], rh[4];
+    uint32_t bmin = 0x7FFF7FFFu, bmax = 0x80008000u;
     const float Ym = s_ty[ly], Yp = s_ty[ly + 1];
+    float qa[4][3], qb[4][3]; // other_point of the two corners
+    bool in_range = true;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         // depth_in[i] * depth_scale (:177): uint16 -> int -> float, one multiply
         const float depth_val = (float)(int)raw[k] * A.scale;
-        p0x[k] = 0;
-        p1x[k] = -1; // empty rectangle
-        p0y[k] = 0;
-        p1y[k] = -1;
-        if (depth_val != 0) {
-            int ax, ay, bx, by;
-            map_corner<DD, DO>(A, depth_val, s_tx[lx + k], Ym, &ax, &ay);
-            map_corner<DD, DO>(A, depth_val, s_tx[lx + k + 1], Yp, &bx, &by);
-            // :241: skip unless the rectangle's corners are inside; an inverted rectangle writes nothing
-            if (!(ax < 0 || ay < 0 || bx >= A.o.width || by >= A.o.height) && ax <= bx && ay <= by) {
-                p0x[k] = ax;
-                p0y[k] = ay;
-                p1x[k] = bx;
-                p1y[k] = by;
-                bx0 = ax < bx0 ? ax : bx0;
-                by0 = ay < by0 ? ay : by0;
-                bx1 = bx > bx1 ? bx : bx1;
-                by1 = by > by1 ? by : by1;
-            }
+        to_other_point<DD>(A, depth_val, s_tx[lx + k], Ym, qa[k]);
+        to_other_point<DD>(A, depth_val, s_tx[lx + k + 1], Yp, qb[k]);
+        // (a pixel without depth is skipped below whatever its quotients are: it does not hold the wave back)
+        in_range &= depth_val == 0 || (div2_guard(qa[k][0], qa[k][1], qa[k][2]) && div2_guard(qb[k][0], qb[k][1], qb[k][2]));
+    }
+    const bool fast_div = __ballot(!in_range) == 0; // uniform
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        p0[k] = 0;
+        rw[k] = -1;
+        rh[k] = -1;
+        int ax, ay, bx, by;
+#if ORBFE_ALIGN_ABLATE >= 3
+        ax = gx + k, ay = gy, bx = gx + k + 1, by = gy + 1;
+#else
+        float ua, va, ub, vb;
+        if (fast_div) {
+            div2_in_range(qa[k][0], qa[k][1], qa[k][2], &ua, &va);
+            div2_in_range(qb[k][0], qb[k][1], qb[k][2], &ub, &vb);
+        } else {
+            ua = qa[k][0] / qa[k][2];
+            va = qa[k][1] / qa[k][2];
+            ub = qb[k][0] / qb[k][2];
+            vb = qb[k][1] / qb[k][2];
+        }
+        to_other_pixel<DO>(A, ua, va, &ax, &ay);
+        to_other_pixel<DO>(A, ub, vb, &bx, &by);
+#endif
+        // :140: no depth, nothing mapped; :241: skip unless the rectangle's corners are inside; an inverted rectangle
+        // writes nothing
+        if (raw[k] != 0 && (float)(int)raw[k] * A.scale != 0 && !(ax < 0 || ay < 0 || bx >= A.o.width || by >= A.o.height) &&
+            ax <= bx && ay <= by) {
+            p0[k] = pk_xy(ax, ay);
+            rw[k] = bx - ax;
+            rh[k] = by - ay;
+            bmin = pk_min_i16(bmin, p0[k]);
+            bmax = pk_max_i16(bmax, pk_xy(bx, by));
         }
     }
     // the tile's bounding box on the output
-    bx0 = wave_min_i32(bx0);
-    by0 = wave_min_i32(by0);
-    bx1 = wave_max_i32(bx1);
-    by1 = wave_max_i32(by1);
-    if ((tid & 63) == 0 && bx1 >= bx0) {
-        atomicMin(&s_box[0], bx0);
-        atomicMin(&s_box[1], by0);
-        atomicMax(&s_box[2], bx1);
-        atomicMax(&s_box[3], by1);
+    bmin = wave_pk_min_i16(bmin);
+    bmax = wave_pk_max_i16(bmax);
+    if ((tid & 63) == 0) {
+        s_box[2 * (tid >> 6)] = bmin;
+        s_box[2 * (tid >> 6) + 1] = bmax;
     }
     __syncthreads();
-    const int wx0 = s_box[0], wy0 = s_box[1], wx1 = s_box[2], wy1 = s_box[3];
-    if (wx1 < wx0) return; // nothing to write (uniform)
-    const int bw = wx1 - wx0 + 1, bh = wy1 - wy0 + 1;
-    const bool fits = (long long)bw * bh <= kAlignWin;
+    bmin = pk_min_i16(pk_min_i16(s_box[0], s_box[2]), pk_min_i16(s_box[4], s_box[6]));
+    bmax = pk_max_i16(pk_max_i16(s_box[1], s_box[3]), pk_max_i16(s_box[5], s_box[7]));
+    const int wx0 = pk_x(bmin) & ~3, wy0 = pk_y(bmin), wx1 = pk_x(bmax), wy1 = pk_y(bmax);
+    if (wx1 < pk_x(bmin)) return; // no rectangle in this tile (uniform)
+    const int bwp = (wx1 - wx0 + 4) & ~3, bh = wy1 - wy0 + 1; // window: bh rows of bwp entries
+    const int nq = bwp >> 2;                                    // quads per row
+    const bool fits = bwp * bh <= kAlignWin;                    // (both < 32768 / bounded by the image: no overflow)
 
     if (fits) {
-        const int n = bw * bh;
-        for (int i = tid; i < n; i += 256) s_win[i] = 0xFFFFFFFFu;
+        const int nquads = nq * bh;
+        for (int i = tid; i < nquads; i += 256) reinterpret_cast<uint4 *>(s_win)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
         __syncthreads();
+#if ORBFE_ALIGN_ABLATE >= 2
+        if (rw[0] == 0x12345) s_win[tid] = raw[1];
+#else
+        const int dump = kAlignWin + tid;
+        int ext = -1; // largest extent of this thread's rectangles
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-            for (int v = p0y[k]; v <= p1y[k]; v++)
-                for (int u = p0x[k]; u <= p1x[k]; u++) atomicMin(&s_win[(v - wy0) * bw + (u - wx0)], raw[k]);
+        for (int k = 0; k < 4; k++) ext = max(ext, max(rw[k], rh[k]));
+        const bool big = ext > 2;
+        const bool any3 = __ballot(ext >= 2) != 0; // uniform: someone in the wave is 3 wide or high
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            // entry (dx, dy) of the 3 x 3 block at p0, or the thread's dump entry when the rectangle does not cover it:
+            // no branch, no EXEC change per entry
+            const int base = (pk_y(p0[k]) - wy0) * bwp + (pk_x(p0[k]) - wx0);
+            const int w = rw[k], h = rh[k];
+            const uint32_t v = raw[k];
+            atomicMin(&s_win[w >= 0 ? base : dump], v);
+            atomicMin(&s_win[w >= 1 ? base + 1 : dump], v); // (w >= 0 implies h >= 0)
+            atomicMin(&s_win[(w >= 0 && h >= 1) ? base + bwp : dump], v);
+            atomicMin(&s_win[(w >= 1 && h >= 1) ? base + bwp + 1 : dump], v);
+            if (any3) {
+                atomicMin(&s_win[w >= 2 ? base + 2 : dump], v);
+                atomicMin(&s_win[(w >= 2 && h >= 1) ? base + bwp + 2 : dump], v);
+                atomicMin(&s_win[(w >= 0 && h >= 2) ? base + 2 * bwp : dump], v);
+                atomicMin(&s_win[(w >= 1 && h >= 2) ? base + 2 * bwp + 1 : dump], v);
+                atomicMin(&s_win[(w >= 2 && h >= 2) ? base + 2 * bwp + 2 : dump], v);
+            }
+        }
+        if (big) { // rectangles beyond 3 x 3 (output much finer than the depth image): the part the block above left out
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                for (int dy = 0; dy <= rh[k]; dy++)
+                    for (int dx = dy > 2 ? 0 : 3; dx <= rw[k]; dx++)
+                        atomicMin(&s_win[(pk_y(p0[k]) - wy0 + dy) * bwp + (pk_x(p0[k]) - wx0) + dx], raw[k]);
+        }
+#endif
         __syncthreads();
-        // a wave per window row, lanes along it: the touched entries of a row leave as neighbouring atomics
+#if ORBFE_ALIGN_ABLATE >= 1
+        if (bwp == 0x12345) out[tid] = s_win[tid] + (uint32_t)(p0[1] + rw[2] + rh[3]);
+        return;
+#endif
+        // a wave per window row, CONSECUTIVE lanes on consecutive entries: the touched entries of a row leave as one or
+        // two fully used cache lines per atomic instruction (a lane per quad -- four strided atomics -- visits every line
+        // four times: measured 2x slower, the L2's atomic rate is per line visit)
         for (int r = tid >> 6; r < bh; r += 4) {
             uint32_t *orow = out + (size_t)(wy0 + r) * A.o.width + wx0;
-            for (int c = tid & 63; c < bw; c += 64) {
-                const uint32_t v = s_win[r * bw + c];
-                if (v != 0xFFFFFFFFu) out_min<ZERO_INIT>(orow + c, v);
+            for (int c = tid & 63; c < bwp; c += 64) {
+                const uint32_t v = s_win[r * bwp + c];
+                if (v != ~0u) out_min<ZERO_INIT>(orow + c, v);
             }
         }
     } else {
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            for (int v = p0y[k]; v <= p1y[k]; v++)
-                for (int u = p0x[k]; u <= p1x[k]; u++) out_min<ZERO_INIT>(out + (size_t)v * A.o.width + u, raw[k]);
+            for (int dy = 0; dy <= rh[k]; dy++)
+                for (int dx = 0; dx <= rw[k]; dx++)
+                    out_min<ZERO_INIT>(out + (size_t)(pk_y(p0[k]) + dy) * A.o.width + pk_x(p0[k]) + dx, raw[k]);
     }
 }
 
@@ -331,7 +482,7 @@ static void launch_splat(uint32_t *out, const uint16_t *depth, const AlignArgs &
 // and then hit by the splat's atomics, so a chunk that fits the 256 MB Infinity Cache pays HBM once per output byte
 static int align_frames(uint32_t *d_out, size_t out_stride, const uint16_t *d_depth, size_t in_stride, int n_frames,
                         float depth_scale, int image_width, int image_height, const orbfe_intrinsics *din,
-                        const orbfe_intrinsics *oin, const orbfe_extrinsics *ext, int frames_per_launch, int force_literal,
+                        const orbfe_intrinsics *oin, const orbfe_extrinsics *ext, int frames_per_launch, bool prefer_zero_init,
                         hipStream_t stream, const char *what)
 {
     if (din->model == 1 || din->model == 3) {
@@ -360,26 +511,55 @@ static int align_frames(uint32_t *d_out, size_t out_stride, const uint16_t *d_de
     A.in_stride = in_stride;
     A.out_stride = out_stride;
     const bool whole = A.rx == oin->width && A.ry == oin->height;
-    const bool zero_init = whole && !force_literal;
+    bool zero_init = whole && prefer_zero_init;
+    if (const char *v = getenv("ORBFE_ALIGN_PROTOCOL")) { // A/B timing and the tests: "zero" | "literal"
+        if (!strcmp(v, "literal")) zero_init = false;
+        else if (!strcmp(v, "zero")) zero_init = whole;
+    }
     const bool vec = din->width % 4 == 0 && A.mx == din->width && (reinterpret_cast<uintptr_t>(d_depth) & 7u) == 0 &&
                      in_stride % 4 == 0;
     const int items = A.tiles_x * A.tiles_y;
-    for (int f0 = 0; f0 < n_frames; f0 += frames_per_launch) {
+    // pipelined form: the clear of chunk c + 1 and the close of chunk c - 1 ride inside chunk c's splat launch as
+    // memory-role workgroups (align_splat_kernel); needs whole frames that are arrays of 16-byte quads
+    const long long px = (long long)oin->width * oin->height;
+    const bool piped = whole && px % 4 == 0 && out_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0 &&
+                       n_frames > frames_per_launch && !getenv("ORBFE_ALIGN_NO_PIPE");
+    const uint32_t fill_value = zero_init ? 0u : kAlignMax;
+    const int n_chunks = (n_frames + frames_per_launch - 1) / frames_per_launch;
+    for (int c = 0; c < n_chunks; c++) {
+        const int f0 = c * frames_per_launch;
         const int n = n_frames - f0 < frames_per_launch ? n_frames - f0 : frames_per_launch;
         uint32_t *o = d_out + (size_t)f0 * out_stride;
         const uint16_t *i = d_depth + (size_t)f0 * in_stride;
         A.n_frames = n;
-        A.grid8 = n >= 8;
+        A.n_slots = n;
+        A.mem_items = A.mem_total = A.n_fill = A.n_close = 0;
+        A.items_total = items;
         const dim3 fgrid((A.rx + 255) / 256, (A.ry + 3) / 4, n);
-        hipLaunchKernelGGL(align_fill_kernel, fgrid, dim3(256), 0, stream, o, zero_init ? 0u : kAlignMax, A);
-        const dim3 grid = A.grid8 ? dim3(8 * items, (n + 7) / 8) : dim3(items, n);
+        if (!piped || c == 0) hipLaunchKernelGGL(align_fill_kernel, fgrid, dim3(256), 0, stream, o, fill_value, A);
+        if (piped) {
+            A.quads = (int)(px / 4);
+            A.mem_items = (A.quads + kAlignMemQuads - 1) / kAlignMemQuads;
+            A.mem_total = zero_init ? A.mem_items : 2 * A.mem_items;
+            A.items_total = items + A.mem_total;
+            A.fill_value = fill_value;
+            const int left = n_frames - (f0 + n);
+            A.n_fill = left < frames_per_launch ? left : frames_per_launch; // the next chunk (0: none)
+            A.n_close = (!zero_init && c > 0) ? frames_per_launch : 0;      // the previous chunk is always a full one
+            A.fill_off = (long long)n * (long long)out_stride;
+            A.close_off = -(long long)frames_per_launch * (long long)out_stride;
+            A.n_slots = n > A.n_fill ? n : A.n_fill;
+            A.n_slots = A.n_slots > A.n_close ? A.n_slots : A.n_close;
+        }
+        A.grid8 = A.n_slots >= 8;
+        const dim3 grid = A.grid8 ? dim3(8 * A.items_total, (A.n_slots + 7) / 8) : dim3(A.items_total, A.n_slots);
         if (zero_init) {
             if (vec) launch_splat<true, true>(o, i, A, grid, stream);
             else launch_splat<true, false>(o, i, A, grid, stream);
         } else {
             if (vec) launch_splat<false, true>(o, i, A, grid, stream);
             else launch_splat<false, false>(o, i, A, grid, stream);
-            hipLaunchKernelGGL(align_unmax_kernel, fgrid, dim3(256), 0, stream, o, A);
+            if (!piped || c == n_chunks - 1) hipLaunchKernelGGL(align_unmax_kernel, fgrid, dim3(256), 0, stream, o, A);
         }
     }
     hipError_t e = hipGetLastError();
@@ -409,9 +589,10 @@ int orbfe_align_depth_to_other(uint32_t *d_aligned_out, const uint16_t *d_depth_
     ARG_CHECK(d_aligned_out && d_depth_in && depth_intrin && other_intrin && depth_to_other);
     ARG_CHECK(image_width > 0 && image_height > 0 && depth_intrin->width > 0 && depth_intrin->height > 0 &&
               other_intrin->width > 0 && other_intrin->height > 0);
+    ARG_CHECK(other_intrin->width <= 32767 && other_intrin->height <= 32767); // output coordinates travel as int16 pairs
     ARG_CHECK(depth_scale == depth_scale && depth_scale - depth_scale == 0.0f); // finite
     return align_frames(d_aligned_out, 0, d_depth_in, 0, 1, depth_scale, image_width, image_height, depth_intrin,
-                        other_intrin, depth_to_other, 1, getenv("ORBFE_ALIGN_LITERAL") != nullptr, S(stream),
+                        other_intrin, depth_to_other, 1, /* one frame: two launches instead of three */ true, S(stream),
                         "align_depth_to_other");
 }
 
@@ -424,6 +605,7 @@ int orbfe_align_depth_batch(uint32_t *d_aligned_out, size_t out_frame_stride, co
     if (n_frames == 0) return ORBFE_OK;
     ARG_CHECK(d_aligned_out && d_depth_in);
     ARG_CHECK(depth_intrin->width > 0 && depth_intrin->height > 0 && other_intrin->width > 0 && other_intrin->height > 0);
+    ARG_CHECK(other_intrin->width <= 32767 && other_intrin->height <= 32767);
     ARG_CHECK(in_frame_stride >= (size_t)depth_intrin->width * depth_intrin->height);
     ARG_CHECK(out_frame_stride >= (size_t)other_intrin->width * other_intrin->height);
     ARG_CHECK(depth_scale == depth_scale && depth_scale - depth_scale == 0.0f);
@@ -431,8 +613,9 @@ int orbfe_align_depth_batch(uint32_t *d_aligned_out, size_t out_frame_stride, co
     const int w = depth_intrin->width > other_intrin->width ? depth_intrin->width : other_intrin->width;
     const int h = depth_intrin->height > other_intrin->height ? depth_intrin->height : other_intrin->height;
     return align_frames(d_aligned_out, out_frame_stride, d_depth_in, in_frame_stride, n_frames, depth_scale, w, h,
-                        depth_intrin, other_intrin, depth_to_other, align_env_int("ORBFE_ALIGN_CHUNK", 64),
-                        getenv("ORBFE_ALIGN_LITERAL") != nullptr, S(stream), "align_depth_batch");
+                        depth_intrin, other_intrin, depth_to_other, align_env_int("ORBFE_ALIGN_CHUNK", 128),
+                        /* many frames: the literal protocol's no-return atomicMin beats the compare-and-swap (measured) */ false,
+                        S(stream), "align_depth_batch");
 }
 
 } // extern "C"

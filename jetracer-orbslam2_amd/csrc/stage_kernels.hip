@@ -708,8 +708,11 @@ int orbfe_reproject_points(float *d_pos_out, const double *d_points_prev, int n,
                            const orbfe_intrinsics *intrin, orbfe_stream_t stream)
 {
     ARG_CHECK(n >= 0 && T_w2c_prev_curr && intrin);
-    if (intrin->model == 2 || intrin->model == 3) { // the reference asserts / needs atan + tan: not on its live path
-        set_thread_error("reproject_points: cannot project to an inverse-distorted or f-theta image (model %d)", intrin->model);
+    // model 2 (inverse Brown-Conrady, what a D4xx colour stream reports) and 4 project WITHOUT distortion in the
+    // reference: its assert against model 2 is commented out (post_processing.cu:15) and only models 1 and 3 have a
+    // branch (:19-38).  Model 3 (f-theta) calls libdevice's double atan / tan: not reproducible, refused.
+    if (intrin->model == 3) {
+        set_thread_error("reproject_points: f-theta projection (post_processing.cu:32-38) needs libdevice's double atan / tan");
         return ORBFE_ERR_UNSUPPORTED;
     }
     if (n == 0) return ORBFE_OK;

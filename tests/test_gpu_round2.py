@@ -256,9 +256,10 @@ def test_match_compact(gpu, oracle_mod, n_prev, n_curr, with_points):
                                            kx.data_ptr(), ky.data_ptr(), cnt.data_ptr(), stream(torch)) == orbfe.ERR_INVALID_ARG
 
 
-@pytest.mark.parametrize("model", [0, 1])
+@pytest.mark.parametrize("model", [0, 1, 2, 4])
 def test_reproject_points(gpu, oracle_mod, model):
-    """kernel_reproject_prev_points (post_processing.cu:72-90): pose * point, then the float projection."""
+    """kernel_reproject_prev_points (post_processing.cu:72-90): pose * point, then the float projection.  Models 2 and 4
+    carry coefficients the projection never reads (post_processing.cu:15-38: only model 1 and 3 have a branch)."""
     torch, orbfe = gpu
     rng = np.random.default_rng(5 + model)
     n = 777
@@ -266,6 +267,8 @@ def test_reproject_points(gpu, oracle_mod, model):
     a = 0.03
     T = np.array([[np.cos(a), 0, np.sin(a), 12.5], [0, 1, 0, -3.25], [-np.sin(a), 0, np.cos(a), 40.0], [0, 0, 0, 1]])
     coeffs = (0.0, 0.0, 0.0, 0.0, 0.0) if model == 0 else (0.11, -0.23, 0.0007, -0.0004, 0.09)
+    if model in (2, 4):  # the same pixels as model 0: the coefficients are not read
+        plain = oracle_mod.Intrinsics(848, 480, 421.5, 237.25, 615.5, 615.25, 0, (C.c_float * 5)())
     intr = orbfe.Intrinsics(848, 480, 421.5, 237.25, 615.5, 615.25, model, (C.c_float * 5)(*coeffs))
     ointr = oracle_mod.Intrinsics(848, 480, 421.5, 237.25, 615.5, 615.25, model, (C.c_float * 5)(*coeffs))
     d_pts = dev(torch, pts)
@@ -275,7 +278,9 @@ def test_reproject_points(gpu, oracle_mod, model):
     ref = oracle_mod.reproject_points(pts, T, ointr)
     np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32))
     assert np.isfinite(ref).all() and ref[:, 0].std() > 10
-    intr.model = 2
+    if model in (2, 4):
+        np.testing.assert_array_equal(ref.view(np.uint32), oracle_mod.reproject_points(pts, T, plain).view(np.uint32))
+    intr.model = 3
     assert orbfe.lib().orbfe_reproject_points(out.data_ptr(), d_pts.data_ptr(), n, Tc, C.byref(intr),
                                               stream(torch)) == orbfe.ERR_UNSUPPORTED
 

@@ -44,13 +44,12 @@ def _align_ref(oracle_mod, depth, scale, iw, ih, d, o, e, before=None):
 @pytest.mark.parametrize("size", [(848, 480, 848, 480), (1280, 720, 1280, 720), (101, 67, 80, 60), (64, 48, 131, 77),
                                   (424, 240, 848, 480)])
 def test_align_depth_stage(gpu, oracle_mod, monkeypatch, size, kind, literal):
-    """The stage entry against the oracle's four literal launches.  `literal` forces the reset-to-max / atomicMin /
-    reset-to-zero protocol (ORBFE_ALIGN_LITERAL); the default is the zero-init protocol.  'wild' scatters a tile's
+    """The stage entry against the oracle's four literal launches.  ORBFE_ALIGN_PROTOCOL forces the reset-to-max /
+    atomicMin / reset-to-zero protocol or the zero-init one (the stage entry's default; the batch entry's is literal).  'wild' scatters a tile's
     rectangles over hundreds of pixels, so its tiles take the straight-to-memory path; (101, 67) rows are not
     8-byte aligned (scalar loads); 424x240 -> 848x480 makes every rectangle 2-3 pixels wide."""
     torch, orbfe = gpu
-    if literal:
-        monkeypatch.setenv("ORBFE_ALIGN_LITERAL", "1")
+    monkeypatch.setenv("ORBFE_ALIGN_PROTOCOL", "literal" if literal else "zero")
     dw, dh, ow, oh = size
     d, o, e, scale = synth.rig(kind, dw, dh, ow, oh)
     depth = synth.depth_frame(dw, dh, index=dw + len(kind))
@@ -58,10 +57,12 @@ def test_align_depth_stage(gpu, oracle_mod, monkeypatch, size, kind, literal):
     got = _align_stage(torch, orbfe, depth, scale, iw, ih, d, o, e)
     want = _align_ref(oracle_mod, depth, scale, iw, ih, d, o, e)
     np.testing.assert_array_equal(got, want)
-    if kind != "wild":
+    if kind == "wild":
+        assert 0.02 < (want != 0).mean() < 0.95
+    elif ow * oh <= dw * dh:  # (a small depth image covers only its share of a larger output)
         assert (want != 0).mean() > 0.3
     else:
-        assert 0.02 < (want != 0).mean() < 0.95
+        assert (want != 0).mean() > 0.2
 
 
 def test_align_depth_grid_smaller_than_the_images(gpu, oracle_mod):
@@ -94,6 +95,27 @@ def test_align_depth_zero_z_and_saturating_conversion(gpu, oracle_mod):
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("log2_scale", [-52, -47, -44, -20, 28, 31, 36])
+def test_align_depth_both_division_paths(gpu, oracle_mod, log2_scale):
+    """The kernel forms x / z and y / z with one shared reciprocal when |x|, |y|, |z| of every lane of the wave lie in
+    [2^-40, 2^40] (v_div_scale is then the identity and the sequence is hipcc's own division, instruction for
+    instruction) and with the plain IEEE division otherwise.  No translation, so the magnitudes scale with depth_scale:
+    these scales put a frame's other_point coordinates below, across and above both ends of the guard -- some waves
+    fast, some slow, some mixed -- and every output pixel must still equal the oracle's (gcc's IEEE division)."""
+    torch, orbfe = gpu
+    w, h = 256, 96
+    d, o, e, _ = synth.rig("d435", w, h)
+    e = (e[0], (0.0, 0.0, 0.0))
+    depth = synth.depth_frame(w, h, 77 + log2_scale, n_rects=10)
+    depth[::7, ::5] = 1      # a spread of magnitudes inside one wave: raw depth 1 .. 4000
+    depth[3::11, 2::9] = 65535
+    scale = 2.0 ** log2_scale
+    got = _align_stage(torch, orbfe, depth, scale, w, h, d, o, e)
+    want = _align_ref(oracle_mod, depth, scale, w, h, d, o, e)
+    np.testing.assert_array_equal(got, want)
+    assert (want != 0).mean() > 0.3
+
+
 def test_align_depth_rejects_what_the_reference_cannot_run(gpu):
     torch, orbfe = gpu
     d, o, e, scale = synth.rig("identity", 32, 32)
@@ -113,18 +135,28 @@ def test_align_depth_rejects_what_the_reference_cannot_run(gpu):
     assert rc == orbfe.ERR_INVALID_ARG
 
 
-@pytest.mark.parametrize("kind,size,n,chunk,pad", [("d435", (848, 480, 848, 480), 19, None, 0),
-                                                  ("d435", (848, 480, 848, 480), 19, 5, 52),
-                                                  ("distorted", (1280, 720, 1280, 720), 9, None, 8),
-                                                  ("wild", (424, 240, 424, 240), 11, 3, 0),
-                                                  ("d435", (101, 67, 80, 60), 10, None, 3),
-                                                  ("identity", (640, 480, 640, 480), 3, None, 0)])
-def test_align_depth_batch(gpu, oracle_mod, monkeypatch, kind, size, n, chunk, pad):
+@pytest.mark.parametrize("kind,size,n,chunk,pad,proto", [("d435", (848, 480, 848, 480), 19, None, 0, None),
+                                                        ("d435", (424, 240, 424, 240), 37, 8, 0, "literal"),   # pipelined: 5 chunks
+                                                        ("d435", (424, 240, 424, 240), 37, 8, 12, "zero"),
+                                                        ("distorted", (212, 120, 424, 240), 21, 4, 0, None),  # chunks < 8 frames
+                                                        ("d435", (101, 67, 80, 60), 23, 8, 3, None),          # not quad-sized: unpiped
+                                                        ("d435", (848, 480, 848, 480), 19, 5, 52, "zero"),
+                                                        ("distorted", (1280, 720, 1280, 720), 9, None, 8, None),
+                                                        ("wild", (424, 240, 424, 240), 11, 3, 0, "zero"),
+                                                        ("wild", (424, 240, 424, 240), 11, 3, 0, "literal"),
+                                                        ("d435", (101, 67, 80, 60), 10, None, 3, None),
+                                                        ("d435", (212, 120, 848, 480), 8, None, 0, None),
+                                                        ("identity", (640, 480, 640, 480), 3, None, 0, None)])
+def test_align_depth_batch(gpu, oracle_mod, monkeypatch, kind, size, n, chunk, pad, proto):
     """n frames per call (one frame per XCD, 8 to a grid row; fewer than 8 the plain grid), padded frame strides,
-    several launches per call (ORBFE_ALIGN_CHUNK): every frame equals the oracle's, the padding is untouched."""
+    several launches per call (ORBFE_ALIGN_CHUNK: with more than one chunk the clear of the next chunk and the close of the
+    previous one ride inside the splat launch), both output protocols; 212x120 -> 848x480 makes every rectangle 4-5
+    pixels wide (beyond the branch-free 3 x 3 block): every frame equals the oracle's, the padding is untouched."""
     torch, orbfe = gpu
     if chunk:
         monkeypatch.setenv("ORBFE_ALIGN_CHUNK", str(chunk))
+    if proto:
+        monkeypatch.setenv("ORBFE_ALIGN_PROTOCOL", proto)
     dw, dh, ow, oh = size
     d, o, e, scale = synth.rig(kind, dw, dh, ow, oh)
     frames = synth.depth_frames(dw, dh, n, first_index=40)
