@@ -380,8 +380,15 @@ __device__ inline int fast_score_packed(const uint8_t *p, uint32_t t2, int arc, 
     uint32_t bright = 0, dark = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) { // pair (ring i, ring i + 8)
+#ifdef ORBFE_DETECT_RING_NOLDS
+        // Profiling aid (results are WRONG): the 16 ring bytes come from registers instead of LDS, the vector instruction
+        // stream is otherwise the same -- the time this build saves is the MOST any rewrite of the ring reads (aligned
+        // dwords, ds_read2, bytes in place ...) could save
+        const uint32_t v0 = (c + (uint32_t)(37 * i + 11)) & 255u, v1 = (c ^ (uint32_t)(29 * i + 5)) & 255u;
+#else
         const uint32_t v0 = p[ring_dy(i) * kPxW + ring_dx(i)];
         const uint32_t v1 = p[ring_dy(i + 8) * kPxW + ring_dx(i + 8)];
+#endif
         const us2 v = U2(v0 | (v1 << 16));
         const us2 ab = ssub(v, hi), ad = ssub(lo, v); // score terms v - (c+t), (c-t) - v, or 0
         sb = U2(U1(sb) + U1(ab)); // 8 terms <= 255 per 16-bit lane: no carry between the lanes, so a full-rate v_add_u32
@@ -1479,7 +1486,12 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
         __syncthreads();
         const int nkp = s_nkp;
         if (DL) cursor = s_cursor;
-        if (nkp == 0) return; // uniform: no (further) keypoint in this tile
+        // uniform: no (further) keypoint in this tile.  WRITE-BACK INVARIANT of the scalar descriptor stores below: this
+        // is the only exit a wave can take AFTER it has issued s_store_dwordx4 (passes 2.. of the DL form), and it is safe
+        // because every pass ends with s_waitcnt lgkmcnt(0) + s_dcache_wb before it loops back here -- a wave never
+        // reaches this return with an unwritten scalar store.  (The STOP_AFTER returns are profiling builds that store
+        // nothing.)  tests/test_gpu_round4.py::test_scalar_descriptor_stores_equal_the_vector_store_build A/Bs the path.
+        if (nkp == 0) return;
         if (ORBFE_DESCRIBE_STOP_AFTER == 1) {
             if (nkp == 12345) records[0].x = (float)s_tile[tid];
             return;

@@ -37,12 +37,15 @@ namespace orbfe {
 // MFMAs), with v_max3_f32 at 14.7 T; the kernel reaches ~12 T.
 constexpr int kMmaS = 16384;
 constexpr float kKeyUnit = 1.0f / (2 * kMmaS); // keys are carried as (integer key) / 2S: a power of two, exact
-constexpr int kMmaLds = 68; // floats per query row in LDS: 64 + 4 keeps writes and b128 reads conflict-free
 constexpr int kRing = 4;                 // candidate blocks in flight per wave
 constexpr int kSlotBytes = 2048 + 256;   // one block: 2 x 1 KB fragments + 16 column keys x 4 copies (a b128 read = the C tuple)
-constexpr int kRingBytes = 4 * kRing * kSlotBytes;
-constexpr int kBestBytes = 128 * kMmaLds * 4; // RB = 8
-constexpr int kMmaLdsBytes = kRingBytes > kBestBytes ? kRingBytes : kBestBytes;
+// NW waves per workgroup (4; 2 = the small-footprint form, 18 KB of LDS instead of 37, for co-residency experiments):
+// floats per query row in LDS: 16 NW + 4 keeps writes and b128 reads conflict-free
+constexpr int mma_lds_row(int nw) { return 16 * nw + 4; }
+constexpr int mma_lds_bytes(int rb, int nw)
+{
+    return nw * kRing * kSlotBytes > 16 * rb * mma_lds_row(nw) * 4 ? nw * kRing * kSlotBytes : 16 * rb * mma_lds_row(nw) * 4;
+}
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -80,14 +83,15 @@ match_expand_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *_
 // RB = query row blocks of 16 per workgroup: 8 (128 queries), or 4 when the call is so small that 128-query
 // workgroups would not even put one on every CU (one to ~15 pairs of 2000: 13 -> 10 us for a single pair,
 // 23 -> 17 us at 4800 keypoints; from 32 pairs on the larger block wins again, measured)
-template <int RB>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
+template <int RB, int NW>
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3)))
 match_mfma_kernel(const uint4 *__restrict__ mexp, const float *__restrict__ mkey, const int32_t *__restrict__ counts,
                   int cap, int capP, int first, int stride, int max_dist, int32_t *__restrict__ out_idx,
                   int32_t *__restrict__ out_dist)
 {
     // the candidate ring while the MFMA loop runs, then (after a barrier) the partial maxima
-    __shared__ __attribute__((aligned(16))) unsigned char s_mem[kMmaLdsBytes];
+    constexpr int kMmaLds = mma_lds_row(NW);
+    __shared__ __attribute__((aligned(16))) unsigned char s_mem[mma_lds_bytes(RB, NW)];
     float *s_best = reinterpret_cast<float *>(s_mem);
     int pk, blk;
     xcd_remap(gridDim.x, gridDim.y, &pk, &blk); // all query blocks of a pair share one L2
@@ -128,10 +132,10 @@ match_mfma_kernel(const uint4 *__restrict__ mexp, const float *__restrict__ mkey
         unsigned char *ring = s_mem + wv * (kRing * kSlotBytes);
         const uint32_t ring_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)ring;
         const uint32_t lds16 = ring_lds + lane * 16, ldsk = ring_lds + (lane & 15) * 16; // this lane's read addresses
-        const int T = wv < nBb ? (nBb - wv + 3) >> 2 : 0; // blocks of this wave
+        const int T = wv < nBb ? (nBb - wv + NW - 1) / NW : 0; // blocks of this wave
         const uint32_t lane_off16 = (uint32_t)lane * 16u, lane_off4 = (uint32_t)(lane >> 2) * 4u;
         auto issue = [&](int s, int t) {
-            int lb = wv + 4 * t;
+            int lb = wv + NW * t;
             lb = lb < nBb ? lb : nBb - 1;
             // uniform base + 32-bit lane offset: the SGPR-base form of the instruction, no 64-bit vector add
             const char *src = reinterpret_cast<const char *>(Eb + (size_t)lb * 128) + lane_off16;
@@ -206,7 +210,9 @@ match_mfma_kernel(const uint4 *__restrict__ mexp, const float *__restrict__ mkey
                 s_best[(m * 16 + 4 * (lane >> 4) + r) * kMmaLds + wv * 16 + (lane & 15)] = best[m][r];
     }
     __syncthreads();
-    const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
+    // 32 partial maxima per thread: two threads per query row with 4 waves, one with 2
+    constexpr int kHalves = NW / 2;
+    const int row = threadIdx.x / kHalves, half = threadIdx.x % kHalves;
     float v = -3e38f;
     if (active && row < kMmaRows) {
         const float4 *src = reinterpret_cast<const float4 *>(s_best + row * kMmaLds + half * 32);
@@ -216,7 +222,7 @@ match_mfma_kernel(const uint4 *__restrict__ mexp, const float *__restrict__ mkey
             v = fmaxf(fmaxf(v, fmaxf(x.x, x.y)), fmaxf(x.z, x.w));
         }
     }
-    v = fmaxf(v, __shfl_xor(v, 1));
+    if (kHalves == 2) v = fmaxf(v, __shfl_xor(v, 1));
     const int i = row0 + row;
     if (half == 0 && row < kMmaRows && i < cap) {
         bool ok = active && i < nA && v > -1e29f;
@@ -241,11 +247,15 @@ void launch_match_mfma(const orbfe_keypoint *d_records, const int32_t *d_counts,
     static_assert(kMmaS == kMmaMaxKeypoints, "key packing");
     hipLaunchKernelGGL(match_expand_kernel, dim3((capP * 8 + 255) / 256, n_frames), dim3(256), 0, stream, d_records,
                        d_counts, cap, capP, mexp, mkey);
-    if ((long long)n_pairs * ((capP + 127) / 128) >= 256) // at least one 128-query workgroup per CU
-        hipLaunchKernelGGL(match_mfma_kernel<8>, dim3((capP + 127) / 128, n_pairs), dim3(256), 0, stream, mexp, mkey,
+    const char *nw = getenv("ORBFE_MATCH_WAVES"); // "2": the 18 KB / 2-wave form (A/B and co-residency probes)
+    if (nw && nw[0] == '2')
+        hipLaunchKernelGGL((match_mfma_kernel<8, 2>), dim3((capP + 127) / 128, n_pairs), dim3(128), 0, stream, mexp, mkey,
+                           d_counts, cap, capP, first, stride, max_dist, d_idx, d_dist);
+    else if ((long long)n_pairs * ((capP + 127) / 128) >= 256) // at least one 128-query workgroup per CU
+        hipLaunchKernelGGL((match_mfma_kernel<8, 4>), dim3((capP + 127) / 128, n_pairs), dim3(256), 0, stream, mexp, mkey,
                            d_counts, cap, capP, first, stride, max_dist, d_idx, d_dist);
     else
-        hipLaunchKernelGGL(match_mfma_kernel<4>, dim3((capP + 63) / 64, n_pairs), dim3(256), 0, stream, mexp, mkey,
+        hipLaunchKernelGGL((match_mfma_kernel<4, 4>), dim3((capP + 63) / 64, n_pairs), dim3(256), 0, stream, mexp, mkey,
                            d_counts, cap, capP, first, stride, max_dist, d_idx, d_dist);
 }
 

@@ -386,3 +386,51 @@ def test_f4_pose_from_hip_matches(gpu, oracle_mod):
     refi = oracle_pose.icp(As, Bs, 20, 0)
     np.testing.assert_allclose(Ti, refi, rtol=0, atol=1e-8 * max(1.0, np.abs(refi).max()))
     np.testing.assert_allclose(Ti[:3, :3], R1, atol=1e-3)
+
+
+# ------------------------------------------------------------------ the scalar descriptor stores, A/B
+def test_scalar_descriptor_stores_equal_the_vector_store_build(gpu, oracle_mod, tmp_path):
+    """describe_tile_kernel writes descriptors with inline-asm s_store_dwordx4 + a hand-placed s_waitcnt / s_dcache_wb
+    (the compiler does not model them).  The -DORBFE_DESC_VECTOR_STORE build (tools/build_variant.sh descvs
+    -DORBFE_DESC_VECTOR_STORE) stores the same words with ordinary vector stores: both builds must give the same record
+    bytes on the dense C2 regime, with descriptor_level (several passes per tile: the exit path after a store) and at
+    a ragged size.  The variant is built on the build host (hipcc), not on the GPU box: skipped when it is not there."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    variant = os.path.join(root, "jetracer-orbslam2_amd", ".variants", "descvs", "liborbfe.so")
+    if not os.path.exists(variant):
+        pytest.skip("build it first: tools/build_variant.sh descvs -DORBFE_DESC_VECTOR_STORE")
+    script = r"""
+import hashlib, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.join(%r, "jetracer-orbslam2_amd"))
+import orbfe
+from orbfe import synth
+out = []
+for (w, h, cfg) in [(640, 480, dict(levels=8, cell=8, min_arc=9, max_features=2000)),
+                    (640, 480, dict(levels=8, cell=8, min_arc=9, max_features=2000, descriptor_level=1)),
+                    (424, 250, dict(levels=5, cell=16, min_arc=10, descriptor_level=1, angle_in_radians=1))]:
+    n = 12
+    frames = synth.frames(w, h, n, first_index=300, kind="rects", **synth.DENSE)
+    ctx = orbfe.Context(w, h, max_batch=n, **cfg)
+    d_in = torch.from_numpy(frames).cuda()
+    rec = torch.zeros(n * ctx.cap * 52, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(n, dtype=torch.int32, device="cuda")
+    for rep in range(3):
+        ctx.extract(d_in.data_ptr(), w, w * h, n, rec.data_ptr(), cnt.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    out.append(hashlib.sha256(rec.cpu().numpy().tobytes()).hexdigest() + ":%%d" %% int(cnt.sum()))
+print(" ".join(out))
+""" % root
+    sigs = []
+    for lib in (None, variant):
+        env = dict(os.environ)
+        env.pop("ORBFE_LIB", None)
+        if lib:
+            env["ORBFE_LIB"] = lib
+        r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        sigs.append(r.stdout.strip().splitlines()[-1])
+    assert sigs[0] == sigs[1], "scalar-store and vector-store builds disagree: %s vs %s" % (sigs[0], sigs[1])
+    assert all(int(s.split(":")[1]) > 1000 for s in sigs[0].split())

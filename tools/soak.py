@@ -19,6 +19,9 @@ CASES = [
     ("c3", 848, 480, 32, dict(levels=8, cell=8, min_arc=9, max_features=2000), dict(mode=1, window=16, md=80, stride=2)),
     ("ref", 640, 480, 32, dict(), dict(mode=0, window=32, md=8, stride=1)),
     ("c5", 3840, 2160, 2, dict(levels=12, cell=16, min_arc=9, max_features=8000), dict(mode=1, window=-1, md=64, stride=1)),
+    # the corrected EXT modes (arithmetic descriptor loop, description on the keypoint's own level)
+    ("c2_fixed", 640, 480, 32, dict(levels=8, cell=8, min_arc=9, max_features=2000, angle_in_radians=1, descriptor_level=1),
+     dict(mode=1, window=-1, md=64, stride=1)),
 ]
 s = torch.cuda.current_stream().cuda_stream
 bad = 0
@@ -48,4 +51,30 @@ for name, w, h, B, cfg, mm in CASES:
             print("MISMATCH", name, it, sig, first)
             break
     print("%s: %d iterations, keypoints %d, matches %d, signature %s" % (name, iters, first[1], int((idx >= 0).sum()), "repeats" if bad == 0 else "CHANGED"))
+# align_depth_to_other (r4): LDS-window + global atomicMin splat, both output protocols, pipelined launches
+import ctypes as C  # noqa: E402
+w, h, B = 848, 480, 24
+d, o, e, scale = synth.rig("d435", w, h)
+mk = lambda t: orbfe.Intrinsics(t[0], t[1], t[2], t[3], t[4], t[5], t[6], (C.c_float * 5)(*t[7]))
+di, oi, ex = mk(d), mk(o), orbfe.Extrinsics((C.c_float * 9)(*e[0]), (C.c_float * 3)(*e[1]))
+src = torch.from_numpy(synth.depth_frames(w, h, B, first_index=900).view(np.int16)).cuda()
+out = torch.zeros((B, h * w), dtype=torch.int32, device="cuda")
+for proto in ("literal", "zero"):
+    os.environ["ORBFE_ALIGN_PROTOCOL"] = proto
+    os.environ["ORBFE_ALIGN_CHUNK"] = "8"
+    first = None
+    for it in range(iters):
+        out.fill_(-1)
+        orbfe.check(orbfe.lib().orbfe_align_depth_batch(out.data_ptr(), w * h, src.data_ptr(), w * h, B, scale, C.byref(di),
+                                                        C.byref(oi), C.byref(ex), s))
+        wts = torch.arange(1, out.numel() + 1, device="cuda", dtype=torch.int64).reshape(out.shape) % 65521
+        sig = int((out.to(torch.int64) * wts).sum())
+        if first is None:
+            first = sig
+        elif sig != first:
+            bad += 1
+            print("MISMATCH align", proto, it, sig, first)
+            break
+    print("align (%s protocol): %d iterations of %d frames, covered %.3f, signature %s" % (
+        proto, iters, B, float((out != 0).float().mean()), "repeats" if sig == first else "CHANGED"))
 sys.exit(1 if bad else 0)
