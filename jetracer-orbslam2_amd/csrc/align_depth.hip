@@ -117,7 +117,7 @@ __device__ inline bool div2_guard(float x, float y, float z)
 // kernel_transfer_pixels (:121-161) for one corner whose normalised depth-image coordinates (before the inverse
 // distortion) are (X, Y): deproject (:57-81), transform (:112-119), project (:23-54), round (:154-155)
 template <bool DD>
-__device__ inline void to_other_point(const AlignArgs &A, float depth_val, float X, float Y, float q[3])
+__device__ inline void to_other_point(const AlignArgs &A, float depth_val, float X, float Y, const float (&rz)[3], float q[3])
 {
     ORBFE_NO_CONTRACT
     float x = X, y = Y;
@@ -134,11 +134,12 @@ __device__ inline void to_other_point(const AlignArgs &A, float depth_val, float
         x = ux;
         y = uy;
     }
-    const float p0 = depth_val * x, p1 = depth_val * y, p2 = depth_val;
+    const float p0 = depth_val * x, p1 = depth_val * y;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
+        // rz[i] = rotation[6 + i] * depth_val, the same product for both corners of the pixel: formed once by the caller
         float t = A.e.rotation[i] * p0 + A.e.rotation[3 + i] * p1;
-        t = t + A.e.rotation[6 + i] * p2;
+        t = t + rz[i];
         t = t + A.e.translation[i];
         q[i] = t;
     }
@@ -299,8 +300,9 @@ align_splat_kernel(uint32_t *__restrict__ out, const uint16_t *__restrict__ dept
     for (int k = 0; k < 4; k++) {
         // depth_in[i] * depth_scale (:177): uint16 -> int -> float, one multiply
         const float depth_val = (float)(int)raw[k] * A.scale;
-        to_other_point<DD>(A, depth_val, s_tx[lx + k], Ym, qa[k]);
-        to_other_point<DD>(A, depth_val, s_tx[lx + k + 1], Yp, qb[k]);
+        const float rz[3] = {A.e.rotation[6] * depth_val, A.e.rotation[7] * depth_val, A.e.rotation[8] * depth_val};
+        to_other_point<DD>(A, depth_val, s_tx[lx + k], Ym, rz, qa[k]);
+        to_other_point<DD>(A, depth_val, s_tx[lx + k + 1], Yp, rz, qb[k]);
         // (a pixel without depth is skipped below whatever its quotients are: it does not hold the wave back)
         in_range &= depth_val == 0 || (div2_guard(qa[k][0], qa[k][1], qa[k][2]) && div2_guard(qb[k][0], qb[k][1], qb[k][2]));
     }

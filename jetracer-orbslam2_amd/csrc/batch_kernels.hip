@@ -378,6 +378,22 @@ __device__ inline int fast_score_packed(const uint8_t *p, uint32_t t2, int arc, 
     const us2 one = U2(0x00010001u);
     us2 sb = U2(0), sd = U2(0);
     uint32_t bright = 0, dark = 0;
+#ifdef ORBFE_DETECT_RING_ROWS3
+    // Experiment (round 4): the three ring pixels of rows y - 3 and y + 3 (x - 1, x, x + 1) as TWO aligned dwords per row
+    // realigned by v_alignbyte instead of three byte reads, their pairs (ring i, ring i + 8) formed by v_perm with constant
+    // selectors: 6 ds_read_u8 + 3 v_lshl_or -> 2 ds_read2_b32 + 2 v_alignbyte + 3 v_perm per candidate
+    uint32_t prow[3];
+    {
+        const uint8_t *qm = p - 3 * kPxW - 1, *qp = p + 3 * kPxW - 1;
+        const uint32_t shm = (uint32_t)(uintptr_t)qm & 3u, shp = (uint32_t)(uintptr_t)qp & 3u;
+        const uint32_t *am = reinterpret_cast<const uint32_t *>(qm - shm), *ap = reinterpret_cast<const uint32_t *>(qp - shp);
+        const uint32_t Tm = __builtin_amdgcn_alignbyte(am[1], am[0], shm); // [ring 7, 8, 9, -]
+        const uint32_t Tp = __builtin_amdgcn_alignbyte(ap[1], ap[0], shp); // [ring 1, 0, 15, -]
+        prow[0] = __builtin_amdgcn_perm(Tm, Tp, 0x0c050c01u); // ring 0 | ring 8 << 16
+        prow[1] = __builtin_amdgcn_perm(Tm, Tp, 0x0c060c00u); // ring 1 | ring 9 << 16
+        prow[2] = __builtin_amdgcn_perm(Tm, Tp, 0x0c020c04u); // ring 7 | ring 15 << 16
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < 8; i++) { // pair (ring i, ring i + 8)
 #ifdef ORBFE_DETECT_RING_NOLDS
@@ -385,11 +401,21 @@ __device__ inline int fast_score_packed(const uint8_t *p, uint32_t t2, int arc, 
         // stream is otherwise the same -- the time this build saves is the MOST any rewrite of the ring reads (aligned
         // dwords, ds_read2, bytes in place ...) could save
         const uint32_t v0 = (c + (uint32_t)(37 * i + 11)) & 255u, v1 = (c ^ (uint32_t)(29 * i + 5)) & 255u;
+        const us2 v = U2(v0 | (v1 << 16));
+#elif defined(ORBFE_DETECT_RING_ROWS3)
+        us2 v;
+        if (i == 0 || i == 1 || i == 7) {
+            v = U2(prow[i == 7 ? 2 : i]);
+        } else {
+            const uint32_t v0 = p[ring_dy(i) * kPxW + ring_dx(i)];
+            const uint32_t v1 = p[ring_dy(i + 8) * kPxW + ring_dx(i + 8)];
+            v = U2(v0 | (v1 << 16));
+        }
 #else
         const uint32_t v0 = p[ring_dy(i) * kPxW + ring_dx(i)];
         const uint32_t v1 = p[ring_dy(i + 8) * kPxW + ring_dx(i + 8)];
-#endif
         const us2 v = U2(v0 | (v1 << 16));
+#endif
         const us2 ab = ssub(v, hi), ad = ssub(lo, v); // score terms v - (c+t), (c-t) - v, or 0
         sb = U2(U1(sb) + U1(ab)); // 8 terms <= 255 per 16-bit lane: no carry between the lanes, so a full-rate v_add_u32
         sd = U2(U1(sd) + U1(ad));
