@@ -218,7 +218,7 @@ align_splat_kernel(uint32_t *__restrict__ out, const uint16_t *__restrict__ dept
     ORBFE_NO_CONTRACT
     // the window (row pitch a multiple of 4 entries, left edge at a multiple of 4 output pixels: 16-byte quads), then
     // one dump entry per thread: the branch-free splat sends what a rectangle does not cover there
-    __shared__ __attribute__((aligned(16))) uint32_t s_win[kAlignWin + 256];
+    __shared__ __attribute__((aligned(16))) uint32_t s_win[kAlignWin + 2 + 256];
     __shared__ float s_tx[kAlignTileW + 1], s_ty[kAlignTileH + 1];
     __shared__ uint32_t s_box[2 * 4]; // per wave: (x0, y0) minima, (x1, y1) maxima, packed
 
@@ -363,7 +363,12 @@ align_splat_kernel(uint32_t *__restrict__ out, const uint16_t *__restrict__ dept
 #if ORBFE_ALIGN_ABLATE >= 2
         if (rw[0] == 0x12345) s_win[tid] = raw[1];
 #else
-        const int dump = kAlignWin + tid;
+        // byte addresses inside s_win; entry (dx, dy) of the 3 x 3 block at p0 lands at row_dy + 4 dx.  What the rectangle
+        // does not cover goes to the thread's dump word instead -- the select is on the ROW address and the + 4 dx rides in
+        // the instruction's offset field (the dump address is pre-biased by - 4 dx; two words of padding keep it inside
+        // the dump area): one v_cndmask per entry, no branch, no EXEC change, no per-entry shift or add
+        unsigned char *wb = reinterpret_cast<unsigned char *>(s_win);
+        const uint32_t dump4 = (uint32_t)(kAlignWin + 2 + tid) * 4u, bwp4 = (uint32_t)bwp * 4u;
         int ext = -1; // largest extent of this thread's rectangles
 #pragma unroll
         for (int k = 0; k < 4; k++) ext = max(ext, max(rw[k], rh[k]));
@@ -371,21 +376,23 @@ align_splat_kernel(uint32_t *__restrict__ out, const uint16_t *__restrict__ dept
         const bool any3 = __ballot(ext >= 2) != 0; // uniform: someone in the wave is 3 wide or high
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            // entry (dx, dy) of the 3 x 3 block at p0, or the thread's dump entry when the rectangle does not cover it:
-            // no branch, no EXEC change per entry
-            const int base = (pk_y(p0[k]) - wy0) * bwp + (pk_x(p0[k]) - wx0);
+            const uint32_t row0 = (uint32_t)((pk_y(p0[k]) - wy0) * bwp + (pk_x(p0[k]) - wx0)) * 4u, row1 = row0 + bwp4;
             const int w = rw[k], h = rh[k];
             const uint32_t v = raw[k];
-            atomicMin(&s_win[w >= 0 ? base : dump], v);
-            atomicMin(&s_win[w >= 1 ? base + 1 : dump], v); // (w >= 0 implies h >= 0)
-            atomicMin(&s_win[(w >= 0 && h >= 1) ? base + bwp : dump], v);
-            atomicMin(&s_win[(w >= 1 && h >= 1) ? base + bwp + 1 : dump], v);
+            auto put = [&](bool covered, uint32_t row, int dx) {
+                atomicMin(reinterpret_cast<uint32_t *>(wb + (covered ? row : dump4 - 4u * (uint32_t)dx)) + dx, v);
+            };
+            put(w >= 0, row0, 0); // (w >= 0 implies h >= 0)
+            put(w >= 1, row0, 1);
+            put(w >= 0 && h >= 1, row1, 0);
+            put(w >= 1 && h >= 1, row1, 1);
             if (any3) {
-                atomicMin(&s_win[w >= 2 ? base + 2 : dump], v);
-                atomicMin(&s_win[(w >= 2 && h >= 1) ? base + bwp + 2 : dump], v);
-                atomicMin(&s_win[(w >= 0 && h >= 2) ? base + 2 * bwp : dump], v);
-                atomicMin(&s_win[(w >= 1 && h >= 2) ? base + 2 * bwp + 1 : dump], v);
-                atomicMin(&s_win[(w >= 2 && h >= 2) ? base + 2 * bwp + 2 : dump], v);
+                const uint32_t row2 = row1 + bwp4;
+                put(w >= 2, row0, 2);
+                put(w >= 2 && h >= 1, row1, 2);
+                put(w >= 0 && h >= 2, row2, 0);
+                put(w >= 1 && h >= 2, row2, 1);
+                put(w >= 2 && h >= 2, row2, 2);
             }
         }
         if (big) { // rectangles beyond 3 x 3 (output much finer than the depth image): the part the block above left out
@@ -404,11 +411,21 @@ align_splat_kernel(uint32_t *__restrict__ out, const uint16_t *__restrict__ dept
         // a wave per window row, CONSECUTIVE lanes on consecutive entries: the touched entries of a row leave as one or
         // two fully used cache lines per atomic instruction (a lane per quad -- four strided atomics -- visits every line
         // four times: measured 2x slower, the L2's atomic rate is per line visit)
-        for (int r = tid >> 6; r < bh; r += 4) {
+        // (the row is wave-uniform: scalar loop control, a scalar row base for the atomics' addresses; two entries per lane
+        // and trip are read before the first atomic goes out; a read past the row's end lands in the next row or in the
+        // dump area -- valid LDS, dropped by the column test)
+        const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        for (int r = wv; r < bh; r += 4) {
             uint32_t *orow = out + (size_t)(wy0 + r) * A.o.width + wx0;
-            for (int c = tid & 63; c < bwp; c += 64) {
-                const uint32_t v = s_win[r * bwp + c];
-                if (v != ~0u) out_min<ZERO_INIT>(orow + c, v);
+            const uint32_t *wrow = s_win + r * bwp;
+            // lane 0 sits on a 128-byte line of the output: every atomic instruction then visits exactly two lines (the
+            // L2's atomic rate is per line visit; an unaligned 64-lane run touches three)
+            const int mis = (int)((reinterpret_cast<uintptr_t>(orow) >> 2) & 31u);
+            for (int c0 = -mis; c0 < bwp; c0 += 128) {
+                const int ca = c0 + lane, cb = ca + 64;
+                const uint32_t va = wrow[ca < 0 ? 0 : ca], vb = wrow[cb];
+                if (ca >= 0 && ca < bwp && va != ~0u) out_min<ZERO_INIT>(orow + ca, va);
+                if (cb < bwp && vb != ~0u) out_min<ZERO_INIT>(orow + cb, vb);
             }
         }
     } else {

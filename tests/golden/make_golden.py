@@ -74,6 +74,19 @@ def digests(oracle, synth):
         T = np.array([[0.9995, 0.0, 0.0316, 12.5], [0.0, 1.0, 0.0, -3.25], [-0.0316, 0.0, 0.9995, 40.0], [0, 0, 0, 1.0]])
         d["reproject"] = sha(oracle.reproject_points(pts_a[:len(a)], T, intr))
         out[name] = d
+    # round 4: align_depth_to_other (cuda-align.cu:366-399) on the synthetic depth frame 0, four rigs, 848x480 and a ragged pair
+    import ctypes as C
+    al = {}
+    for kind in ("identity", "d435", "distorted", "wild"):
+        for (dw, dh, ow, oh) in ((848, 480, 848, 480), (101, 67, 80, 60)):
+            dk, ok, ek, scale = synth.rig(kind, dw, dh, ow, oh)
+            mk = lambda t: oracle.Intrinsics(t[0], t[1], t[2], t[3], t[4], t[5], t[6], (C.c_float * 5)(*t[7]))
+            ex = oracle.Extrinsics((C.c_float * 9)(*ek[0]), (C.c_float * 3)(*ek[1]))
+            depth = synth.depth_frame(dw, dh, 0)
+            aligned, pm = oracle.align_depth_to_other(depth, scale, max(dw, ow), max(dh, oh), mk(dk), mk(ok), ex, want_map=True)
+            al["%s_%dx%d_to_%dx%d" % (kind, dw, dh, ow, oh)] = {"depth": sha(depth), "aligned": sha(aligned), "map": sha(pm),
+                                                              "covered": int((aligned != 0).sum())}
+    out["align_depth"] = al
     return out
 
 

@@ -95,6 +95,46 @@ def np_align(depth, scale, image_w, image_h, d, o, e):
     return out, np.stack([np.stack([ax, ay], -1), np.stack([bx, by], -1)])
 
 
+def random_case(rng, trial):
+    """One seeded random (depth intrinsics, other intrinsics, extrinsics, scale, frames): focal lengths 0.3 .. 1.2 x the
+    width on both sides (rectangles from 1 x 1 to 5 x 5 pixels), principal points off centre, small random rotations about
+    all three axes, translations up to 0.3 m, random distortion models and coefficients, hole rates, depth ranges, sizes."""
+    dw, dh = int(rng.integers(8, 300)), int(rng.integers(8, 200))
+    ow, oh = (dw, dh) if rng.random() < 0.4 else (int(rng.integers(8, 400)), int(rng.integers(8, 260)))
+    n = int(rng.integers(1, 12))
+    co = lambda: tuple(float(v) for v in rng.normal(0, [0.06, 0.08, 0.001, 0.001, 0.02]))
+    d = (dw, dh, dw * rng.uniform(0.4, 0.6), dh * rng.uniform(0.4, 0.6), dw * rng.uniform(0.3, 1.2), dw * rng.uniform(0.3, 1.2),
+         int(rng.choice([0, 2, 4])), co())
+    o = (ow, oh, ow * rng.uniform(0.4, 0.6), oh * rng.uniform(0.4, 0.6), ow * rng.uniform(0.3, 1.2), ow * rng.uniform(0.3, 1.2),
+         int(rng.choice([0, 1, 2, 4])), co())
+    a, b, c = rng.normal(0, 0.03, 3)
+    rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+    ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+    rz = np.array([[np.cos(c), -np.sin(c), 0], [np.sin(c), np.cos(c), 0], [0, 0, 1]])
+    rot = (rz @ ry @ rx).astype(np.float32)
+    e = (tuple(float(v) for v in rot.T.reshape(-1)), tuple(float(v) for v in rng.uniform(-0.3, 0.3, 3)))  # column-major
+    scale = float(rng.choice([0.001, 0.0001, 0.00025]))
+    frames = synth.depth_frames(dw, dh, n, first_index=1000 + 13 * trial, n_rects=int(rng.integers(0, 30)),
+                                holes=float(rng.uniform(0, 0.6)), near=int(rng.integers(1, 2000)), far=int(rng.integers(2000, 60000)))
+    return d, o, e, scale, frames
+
+
+def test_fuzz_against_the_numpy_definition(oracle_mod):
+    """24 seeded random rigs (random_case): map and image of the C restatement equal the numpy float32 definition."""
+    rng = np.random.default_rng(20261005)
+    covered = []
+    for trial in range(24):
+        d, o, e, scale, frames = random_case(rng, trial)
+        iw, ih = max(d[0], o[0]), max(d[1], o[1])
+        out, pm = oracle_mod.align_depth_to_other(frames[0], scale, iw, ih, intr(oracle_mod, d), intr(oracle_mod, o),
+                                                  extr(oracle_mod, e), want_map=True)
+        want, wmap = np_align(frames[0], scale, iw, ih, d, o, e)
+        np.testing.assert_array_equal(pm, wmap.astype(np.int32), err_msg="trial %d" % trial)
+        np.testing.assert_array_equal(out, want, err_msg="trial %d" % trial)
+        covered.append((out != 0).mean())
+    assert max(covered) > 0.8 and min(covered) < 0.2  # dense and sparse outcomes both occur
+
+
 def test_exact_case_worked_by_hand(oracle_mod):
     """fx = fy = 1, pp = 0, identity motion, depth_val a power of two: every float operation is exact, so corner
     -0.5 of pixel (x, y) maps to int((x - 0.5) + 0.5) = x and corner +0.5 to x + 1 (cuda-align.cu:143-155): the pixel's

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 from orbfe import synth
-from test_align_oracle import extr, intr
+from test_align_oracle import extr, intr, random_case
 from test_gpu_parity import dev, stream
 
 pytestmark = pytest.mark.gpu
@@ -174,6 +174,27 @@ def test_align_depth_batch(gpu, oracle_mod, monkeypatch, kind, size, n, chunk, p
         want = _align_ref(oracle_mod, frames[f], scale, max(dw, ow), max(dh, oh), d, o, e)
         np.testing.assert_array_equal(got[f, :ow * oh].reshape(oh, ow), want, err_msg="frame %d" % f)
     assert (got[:, ow * oh:] == 0x5A5A5A5A).all()
+
+
+def test_align_depth_fuzz(gpu, oracle_mod):
+    """Seeded random rigs and sizes (test_align_oracle.random_case) through the batch entry: rectangles from 1 x 1 to 5 x 5
+    pixels, all distortion models, sizes that are and are not multiples of the 64 x 16 tile or of 4, 1 .. 11 frames.  Every
+    frame must equal the oracle's."""
+    torch, orbfe = gpu
+    rng = np.random.default_rng(int(os.environ.get("ORBFE_FUZZ_SEED", "20261005")))
+    for trial in range(int(os.environ.get("ORBFE_FUZZ_TRIALS", "24"))):
+        d, o, e, scale, frames = random_case(rng, trial)
+        (dw, dh), (ow, oh), n = d[:2], o[:2], len(frames)
+        d_src = dev(torch, frames.view(np.int16))
+        d_out = torch.full((n, ow * oh), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+        orbfe.check(orbfe.lib().orbfe_align_depth_batch(d_out.data_ptr(), ow * oh, d_src.data_ptr(), dw * dh, n, scale,
+                                                        C.byref(intr(orbfe, d)), C.byref(intr(orbfe, o)), C.byref(extr(orbfe, e)),
+                                                        stream(torch)))
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy().view(np.uint32)
+        for f in range(n):
+            want = _align_ref(oracle_mod, frames[f], scale, max(dw, ow), max(dh, oh), d, o, e)
+            np.testing.assert_array_equal(got[f].reshape(oh, ow), want, err_msg="trial %d frame %d: %r %r" % (trial, f, d, o))
 
 
 def test_align_depth_feeds_keypoint_pixel_to_point(gpu, oracle_mod):
