@@ -17,12 +17,15 @@
 //   - atomicMin is order-free, so the result is deterministic and equals the reference's: min raw depth over the depth
 //     pixels whose rectangle covers the output pixel, 0 where none does.
 // Two exact forms of the output protocol:
-//   zero-init form (whole output inside the launch grid, the normal case): output cleared to 0, "0 = nothing yet", a
-//     window entry v lands by  old = CAS(p, 0, v); if (old != 0 && v < old) atomicMin(p, v)  -- raw depths that reach a
-//     splat are >= 1 (depth 0 is skipped, :140), so 0 is free to mean "empty" and no closing pass is needed: 2 launches;
-//   literal form: reset the grid's part of the output to 9999999, atomicMin, 9999999 -> 0 on the same part: 3 launches;
-//     needed only when the intrinsics' sizes exceed the grid made from image_width / image_height (:378-380), where the
-//     reference leaves what the caller's buffer held (min'ed with any splat) -- reproduced.
+//   literal form (the default of both entry points): reset the grid's part of the output to 9999999, atomicMin WITHOUT
+//     return, 9999999 -> 0 on the same part: 3 launches.  Also what reproduces the reference where the intrinsics' sizes
+//     exceed the grid made from image_width / image_height (:378-380): output pixels beyond it keep min(what the caller's
+//     buffer held, splats).
+//   zero-init form (ORBFE_ALIGN_PROTOCOL=zero; whole output inside the launch grid only): output cleared to 0, "0 =
+//     nothing yet", a window entry v lands by  old = CAS(p, 0, v); if (old != 0 && v < old) atomicMin(p, v)  -- raw depths
+//     that reach a splat are >= 1 (depth 0 is skipped, :140), so 0 is free to mean "empty" and no closing pass is needed:
+//     2 launches.  Built first, kept as the A/B: atomics WITH return cost more than the closing pass saves (3.09 against
+//     2.10 ms per 1024 frames, 16.1 against 11.4 us for a single frame).
 // Arithmetic: float, left to right as written in the reference, no contraction (ORBFE_NO_CONTRACT; the build has
 // -ffp-contract=off), IEEE division; static_cast<int>(v + 0.5f) is v_cvt_i32_f32 = truncation, saturating, NaN -> 0,
 // exactly CUDA's cvt.rzi.s32.f32.  Parity with the reference is unpinned at the ulp level (nvcc may fuse a*b+c).
@@ -611,8 +614,8 @@ int orbfe_align_depth_to_other(uint32_t *d_aligned_out, const uint16_t *d_depth_
     ARG_CHECK(other_intrin->width <= 32767 && other_intrin->height <= 32767); // output coordinates travel as int16 pairs
     ARG_CHECK(depth_scale == depth_scale && depth_scale - depth_scale == 0.0f); // finite
     return align_frames(d_aligned_out, 0, d_depth_in, 0, 1, depth_scale, image_width, image_height, depth_intrin,
-                        other_intrin, depth_to_other, 1, /* one frame: two launches instead of three */ true, S(stream),
-                        "align_depth_to_other");
+                        other_intrin, depth_to_other, 1, /* literal protocol: 11.4 us per 848x480 frame against 16.1 for the 2-launch
+                        zero-init form (tools/stage_latency.py) */ false, S(stream), "align_depth_to_other");
 }
 
 int orbfe_align_depth_batch(uint32_t *d_aligned_out, size_t out_frame_stride, const uint16_t *d_depth_in,

@@ -45,7 +45,7 @@ def _align_ref(oracle_mod, depth, scale, iw, ih, d, o, e, before=None):
                                   (424, 240, 848, 480)])
 def test_align_depth_stage(gpu, oracle_mod, monkeypatch, size, kind, literal):
     """The stage entry against the oracle's four literal launches.  ORBFE_ALIGN_PROTOCOL forces the reset-to-max /
-    atomicMin / reset-to-zero protocol or the zero-init one (the stage entry's default; the batch entry's is literal).  'wild' scatters a tile's
+    atomicMin / reset-to-zero protocol (the default) or the zero-init one (the A/B form).  'wild' scatters a tile's
     rectangles over hundreds of pixels, so its tiles take the straight-to-memory path; (101, 67) rows are not
     8-byte aligned (scalar loads); 424x240 -> 848x480 makes every rectangle 2-3 pixels wide."""
     torch, orbfe = gpu

@@ -68,3 +68,28 @@ for tag, cfg in (("reference regime", dict(levels=levels, cell=32, min_arc=12)),
     torch.cuda.synchronize()
     print("batch API, batch of 1, %s: %.1f us per frame (%d keypoints)"
           % (tag, e0.elapsed_time(e1) / n * 1e3, int(cnt.item())))
+
+# r4: one depth frame 848x480 through the stage entry of align_depth_to_other (what buildStream.cpp:385 issues per frame),
+# under both output protocols (zero-init = 2 launches, the stage entry's default; literal = 3)
+import ctypes as C  # noqa: E402
+import os  # noqa: E402
+dw, dh = 848, 480
+d, o, e, scale = synth.rig("d435", dw, dh)
+mk = lambda t: orbfe.Intrinsics(t[0], t[1], t[2], t[3], t[4], t[5], t[6], (C.c_float * 5)(*t[7]))
+di, oi, ex = mk(d), mk(o), orbfe.Extrinsics((C.c_float * 9)(*e[0]), (C.c_float * 3)(*e[1]))
+d_depth = torch.from_numpy(synth.depth_frame(dw, dh, 3).view(np.int16)).cuda()
+d_al = torch.zeros((dh, dw), dtype=torch.int32, device="cuda")
+for proto in ("zero", "literal"):
+    os.environ["ORBFE_ALIGN_PROTOCOL"] = proto
+    call = lambda: orbfe.check(orbfe.lib().orbfe_align_depth_to_other(d_al.data_ptr(), d_depth.data_ptr(), None, scale, dw, dh,
+                                                                      C.byref(di), C.byref(oi), C.byref(ex), s))
+    for _ in range(20):
+        call()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    print("align_depth_to_other, one %dx%d depth frame, %s protocol: %.1f us per frame" % (dw, dh, proto, e0.elapsed_time(e1) / n * 1e3))
+os.environ.pop("ORBFE_ALIGN_PROTOCOL", None)
