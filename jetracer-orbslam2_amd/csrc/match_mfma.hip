@@ -210,32 +210,35 @@ match_mfma_kernel(const uint4 *__restrict__ mexp, const float *__restrict__ mkey
                 s_best[(m * 16 + 4 * (lane >> 4) + r) * kMmaLds + wv * 16 + (lane & 15)] = best[m][r];
     }
     __syncthreads();
-    // 32 partial maxima per thread: two threads per query row with 4 waves, one with 2
-    constexpr int kHalves = NW / 2;
-    const int row = threadIdx.x / kHalves, half = threadIdx.x % kHalves;
-    float v = -3e38f;
-    if (active && row < kMmaRows) {
-        const float4 *src = reinterpret_cast<const float4 *>(s_best + row * kMmaLds + half * 32);
+    // the 16 NW partial maxima of a query row (NW waves x 16 column classes): two threads per row with 4 waves (32 floats
+    // each, met by one shuffle), one thread per row with 2 waves, one thread for two rows with 1 wave
+    constexpr int kTPR = NW >= 4 ? 2 : 1, kFPT = 16 * NW / kTPR, kRowStep = 64 * NW / kTPR;
+    for (int row = (int)threadIdx.x / kTPR; row < kMmaRows; row += kRowStep) {
+        const int part = (int)threadIdx.x % kTPR;
+        float v = -3e38f;
+        if (active) {
+            const float4 *src = reinterpret_cast<const float4 *>(s_best + row * kMmaLds + part * kFPT);
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const float4 x = src[k];
-            v = fmaxf(fmaxf(v, fmaxf(x.x, x.y)), fmaxf(x.z, x.w));
+            for (int k = 0; k < kFPT / 4; k++) {
+                const float4 x = src[k];
+                v = fmaxf(fmaxf(v, fmaxf(x.x, x.y)), fmaxf(x.z, x.w));
+            }
         }
-    }
-    if (kHalves == 2) v = fmaxf(v, __shfl_xor(v, 1));
-    const int i = row0 + row;
-    if (half == 0 && row < kMmaRows && i < cap) {
-        bool ok = active && i < nA && v > -1e29f;
-        int bj = -1, bd = -1;
-        if (ok) {
-            const int nk = -(int)(v * (2 * kMmaS));                                       // S * (dist - |a_i|) + j
-            const int pop_a = (-(int)(mkey[(size_t)p * capP + i] * (2 * kMmaS))) >> 14; // |a_i|
-            bj = nk & (kMmaS - 1);
-            bd = pop_a + (nk >> 14);
-            ok = bd <= max_dist;
+        if (kTPR == 2) v = fmaxf(v, __shfl_xor(v, 1));
+        const int i = row0 + row;
+        if (part == 0 && i < cap) {
+            bool ok = active && i < nA && v > -1e29f;
+            int bj = -1, bd = -1;
+            if (ok) {
+                const int nk = -(int)(v * (2 * kMmaS));                                       // S * (dist - |a_i|) + j
+                const int pop_a = (-(int)(mkey[(size_t)p * capP + i] * (2 * kMmaS))) >> 14; // |a_i|
+                bj = nk & (kMmaS - 1);
+                bd = pop_a + (nk >> 14);
+                ok = bd <= max_dist;
+            }
+            out_idx[(size_t)pk * cap + i] = ok ? bj : -1;
+            if (out_dist) out_dist[(size_t)pk * cap + i] = ok ? bd : -1;
         }
-        out_idx[(size_t)pk * cap + i] = ok ? bj : -1;
-        if (out_dist) out_dist[(size_t)pk * cap + i] = ok ? bd : -1;
     }
 }
 
@@ -250,6 +253,9 @@ void launch_match_mfma(const orbfe_keypoint *d_records, const int32_t *d_counts,
     const char *nw = getenv("ORBFE_MATCH_WAVES"); // "2": the 18 KB / 2-wave form (A/B and co-residency probes)
     if (nw && nw[0] == '2')
         hipLaunchKernelGGL((match_mfma_kernel<8, 2>), dim3((capP + 127) / 128, n_pairs), dim3(128), 0, stream, mexp, mkey,
+                           d_counts, cap, capP, first, stride, max_dist, d_idx, d_dist);
+    else if (nw && nw[0] == '1')
+        hipLaunchKernelGGL((match_mfma_kernel<8, 1>), dim3((capP + 127) / 128, n_pairs), dim3(64), 0, stream, mexp, mkey,
                            d_counts, cap, capP, first, stride, max_dist, d_idx, d_dist);
     else if ((long long)n_pairs * ((capP + 127) / 128) >= 256) // at least one 128-query workgroup per CU
         hipLaunchKernelGGL((match_mfma_kernel<8, 4>), dim3((capP + 127) / 128, n_pairs), dim3(256), 0, stream, mexp, mkey,
