@@ -15,7 +15,11 @@
 //     to memory, one atomic per output pixel and tile instead of one per covered pixel and depth pixel; a tile whose
 //     rectangles are scattered (degenerate extrinsics, depth discontinuities across metres) splats straight to memory.
 //   - atomicMin is order-free, so the result is deterministic and equals the reference's: min raw depth over the depth
-//     pixels whose rectangle covers the output pixel, 0 where none does.
+//     pixels whose rectangle covers the output pixel, 0 where none does;
+//   - the two quotients of a projection share one reciprocal when that is provably the compiler's own division sequence
+//     (div2_in_range / div2_guard below), the whole wave takes the plain `/` otherwise;
+//   - with more than one chunk of frames per call, the reset of the next chunk and the close of the previous one are
+//     carried by extra workgroups of the splat launch itself (memory-bound roles beside the vector-ALU-bound tiles).
 // Two exact forms of the output protocol:
 //   literal form (the default of both entry points): reset the grid's part of the output to 9999999, atomicMin WITHOUT
 //     return, 9999999 -> 0 on the same part: 3 launches.  Also what reproduces the reference where the intrinsics' sizes
