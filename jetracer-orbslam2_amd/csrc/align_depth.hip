@@ -548,8 +548,12 @@ static int align_frames(uint32_t *d_out, size_t out_stride, const uint16_t *d_de
     // pipelined form: the clear of chunk c + 1 and the close of chunk c - 1 ride inside chunk c's splat launch as
     // memory-role workgroups (align_splat_kernel); needs whole frames that are arrays of 16-byte quads
     const long long px = (long long)oin->width * oin->height;
+    // (the kernel finds a work item's role with 32-bit arithmetic: item * memory items per slot must stay below 2^32 --
+    // frames beyond ~8000 x 8000 take the unpipelined launches)
+    const unsigned long long mem_items_ll = (unsigned long long)((px / 4 + kAlignMemQuads - 1) / kAlignMemQuads);
     const bool piped = whole && px % 4 == 0 && out_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0 &&
-                       n_frames > frames_per_launch && !getenv("ORBFE_ALIGN_NO_PIPE");
+                       n_frames > frames_per_launch && !getenv("ORBFE_ALIGN_NO_PIPE") &&
+                       ((unsigned long long)items + 2 * mem_items_ll) * (2 * mem_items_ll) < 0xFFFFFFFFull;
     const uint32_t fill_value = zero_init ? 0u : kAlignMax;
     const int n_chunks = (n_frames + frames_per_launch - 1) / frames_per_launch;
     for (int c = 0; c < n_chunks; c++) {

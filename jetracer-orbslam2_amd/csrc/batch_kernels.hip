@@ -614,8 +614,13 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
         const uint32_t cm = inner ? kH8 : colmask(x0 - 4 + 4 * q);
         const uint32_t *row = s_px32 + (r0 + 3) * kPxDw + q;
         static_assert(kMainTrips == 4, "a lane's trips are the rows of its 4 x 4 block");
+        // a wave's band of 16 rows starts at image row y0 + 16 wv: in the last row of tiles of a level the bands that lie
+        // entirely at or below H - 3 hold no testable pixel (640x480: half of each of the 10 bottom tiles of level 0) and
+        // skip their four compass trips -- wave-uniform, so a scalar branch (r4)
+        const int n_trips = (y0 + 16 * wv < H - 3) ? kMainTrips : 0;
 #pragma unroll
         for (int trip = 0; trip < kMainTrips; trip++, row += kPxDw) {
+            if (trip >= n_trips) break;
             const uint32_t C = row[0], L = row[-1], Rr = row[1];
             const uint32_t Nd = row[-3 * kPxDw], Sd = row[3 * kPxDw];
             const uint32_t Wd = __builtin_amdgcn_alignbyte(C, L, 1);  // bytes x-3 of the 4 pixels
