@@ -42,6 +42,31 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(orbfe.Soa) == 48
     assert orbfe.KEYPOINT_DTYPE.itemsize == 52
     assert orbfe.KEYPOINT_DTYPE.fields["desc"][1] == 20
+    # rs2_intrinsics / rs2_extrinsics as the reference's kernels read them (cuda-align.cu:57-119): 12 x 4 bytes each
+    assert C.sizeof(orbfe.Intrinsics) == 48 and orbfe.Intrinsics.model.offset == 24 and orbfe.Intrinsics.coeffs.offset == 28
+    assert C.sizeof(orbfe.Extrinsics) == 48 and orbfe.Extrinsics.translation.offset == 36
+
+
+def test_align_depth_argument_validation_needs_no_device():
+    """orbfe_align_depth_to_other / _batch reject bad arguments and the models the reference cannot run before any HIP
+    call (host-side checks), so the contract is testable without a GPU."""
+    import orbfe
+    lib = orbfe.lib()
+    ok = orbfe.Intrinsics(64, 48, 32.0, 24.0, 50.0, 50.0, 0, (C.c_float * 5)())
+    ex = orbfe.Extrinsics((C.c_float * 9)(1, 0, 0, 0, 1, 0, 0, 0, 1), (C.c_float * 3)())
+    fake = 0x1000  # never dereferenced: every case below is refused first
+    call = lambda scale, d, o: lib.orbfe_align_depth_to_other(fake, fake, None, scale, 64, 48, C.byref(d), C.byref(o), C.byref(ex), None)
+    assert lib.orbfe_align_depth_to_other(None, fake, None, 0.001, 64, 48, C.byref(ok), C.byref(ok), C.byref(ex), None) == orbfe.ERR_INVALID_ARG
+    assert call(float("inf"), ok, ok) == orbfe.ERR_INVALID_ARG
+    for dm, om in ((1, 0), (3, 0), (0, 3)):
+        d = orbfe.Intrinsics(64, 48, 32.0, 24.0, 50.0, 50.0, dm, (C.c_float * 5)())
+        o = orbfe.Intrinsics(64, 48, 32.0, 24.0, 50.0, 50.0, om, (C.c_float * 5)())
+        assert call(0.001, d, o) == orbfe.ERR_UNSUPPORTED
+        assert b"align_depth_to_other" in lib.orbfe_last_error(None)
+    big = orbfe.Intrinsics(40000, 48, 32.0, 24.0, 50.0, 50.0, 0, (C.c_float * 5)())
+    assert call(0.001, ok, big) == orbfe.ERR_INVALID_ARG  # output coordinates travel as int16 pairs
+    assert lib.orbfe_align_depth_batch(fake, 10, fake, 64 * 48, 2, 0.001, C.byref(ok), C.byref(ok), C.byref(ex), None) == orbfe.ERR_INVALID_ARG  # stride < frame
+    assert lib.orbfe_align_depth_batch(None, 0, None, 0, 0, 0.001, C.byref(ok), C.byref(ok), C.byref(ex), None) == orbfe.OK  # nothing to do
 
 
 def test_no_cpu_fallback_without_a_device():
