@@ -420,6 +420,135 @@ def align_bench(args, torch, np, orbfe, dev, json_out):
     json_out.flush()
 
 
+def ingest_bench(torch, np, orbfe, synth, dev, mode, scene, frames_per_slot, passes=12, slots=3, rgb=False, pageable=False):
+    """SURVEY.md 8f-1, the staging half (include/orbfe_ingest.h; buildStream.cpp:376-381, :399-406, :462-466, :483-487):
+    the SAME step as the headline (orbfe_extract + orbfe_match_batch), but the frames start in pinned HOST memory and the
+    records, counts and matcher outputs end there.  Three figures per slot of `frames_per_slot` frames:
+      copy     the slot's upload and download alone, both directions at once (full duplex), no kernels;
+      compute  extraction + matching on the slot's device-resident frames, no copies;
+      pipelined  the ring running: upload of slot s + 1 / kernels of slot s / download of slot s - 1 overlapped.
+    overlap_efficiency = max(copy, compute) / pipelined (1 = perfect overlap; the target is >= 0.9), and the side that
+    bounds the configuration is named.  The pinned-copy peaks are measured here, on this box, with plain hipMemcpyAsync
+    of 256 MiB buffers (torch pinned tensors), one direction at a time and both at once."""
+    m = MODES[mode]
+    w, h = m["width"], m["height"]
+    mm = m["match"]
+    F = frames_per_slot
+    ch = 3 if rgb else 1
+    ctx = orbfe.Context(w, h, max_batch=F, device=dev.index or 0, **m["cfg"])
+    ing = orbfe.Ingest(ctx, F, slots=slots, channels=ch, match_mode=mm["mode"] if mm else -1, match_window=mm["window"] if mm else -1,
+                       match_max_distance=mm["max_distance"] if mm else 256, download_matches=2 if mm else 0)
+    n_distinct = min(32, F)
+    for sl in range(slots):  # every slot holds other scenes
+        base = make_scenes(synth, mode, scene, n_distinct, 50000 + 1000 * sl)
+        fr = base[np.arange(F) % len(base)]
+        if rgb:
+            fr = (fr.astype(np.int16)[..., None] + np.array([3, 0, -3], np.int16)).clip(0, 255).astype(np.uint8)
+        ing.host_frames(sl)[:] = fr
+    pageable_src = np.ascontiguousarray(ing.host_frames(0)).copy() if pageable else None
+
+    def submit(sl):
+        if pageable:
+            ing.submit_from(sl, pageable_src)
+        else:
+            ing.submit(sl, F)
+
+    # warm-up: every slot once (first-touch of the pinned pages, clocks)
+    for sl in range(slots):
+        submit(sl)
+    for sl in range(slots):
+        ing.wait(sl)
+    t_first = ing.timing(0)
+    up_bytes, down_bytes = t_first["upload_bytes"], t_first["download_bytes"]
+    # pipelined: `passes` slot passes through the ring, the host only submits and waits
+    t0 = time.perf_counter()
+    kp = 0
+    for i in range(passes):
+        sl = i % slots
+        if i >= slots:
+            _, cnt, _, _ = ing.wait(sl)
+            kp += int(cnt.sum())
+        submit(sl)
+    for i in range(passes, passes + slots):
+        sl = i % slots
+        _, cnt, _, _ = ing.wait(sl)
+        kp += int(cnt.sum())
+    t_pipe = (time.perf_counter() - t0) / passes
+    per_slot = [ing.timing(sl) for sl in range(slots)]
+    up_ms = sum(t["upload_ms"] for t in per_slot) / slots      # inside the running pipeline, from the ring's own events
+    cmp_ms = sum(t["compute_ms"] for t in per_slot) / slots
+    down_ms = sum(t["download_ms"] for t in per_slot) / slots
+    # compute alone: the same calls on the slot's resident device frames, torch's stream, nothing else running
+    d_frames, d_rec, d_cnt, d_idx, d_dst = ing.device_buffers(0)
+    s = torch.cuda.current_stream().cuda_stream
+
+    def compute_once():
+        if rgb:
+            ctx.extract_rgb(d_frames, 3 * w, 3 * w * h, F, d_rec, d_cnt, None, s)
+        else:
+            ctx.extract(d_frames, w, w * h, F, d_rec, d_cnt, None, s)
+        if mm:
+            ctx.match_batch(d_rec, d_cnt, F, mm["mode"], mm["window"], mm["max_distance"], d_idx, d_dst, s)
+    for _ in range(3):
+        compute_once()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = max(5, min(200, int(50.0 / max(cmp_ms, 1e-3))))
+    e0.record()
+    for _ in range(reps):
+        compute_once()
+    e1.record()
+    torch.cuda.synchronize()
+    t_compute = e0.elapsed_time(e1) / reps * 1e-3
+    ing.close()
+    ctx.close()
+
+    # copies alone (pinned torch tensors = hipHostMalloc): peaks at 256 MiB, then this slot's own sizes in both directions at once
+    def copy_time(h2d_bytes, d2h_bytes, reps):
+        hs = torch.empty(max(h2d_bytes, 1), dtype=torch.uint8).pin_memory()
+        ds = torch.empty(max(h2d_bytes, 1), dtype=torch.uint8, device=dev)
+        hd = torch.empty(max(d2h_bytes, 1), dtype=torch.uint8).pin_memory()
+        dd = torch.zeros(max(d2h_bytes, 1), dtype=torch.uint8, device=dev)
+        hs.zero_(); hd.zero_()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        best = None
+        for attempt in range(2):  # the first run touches the pages
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                if h2d_bytes:
+                    with torch.cuda.stream(s1):
+                        ds.copy_(hs, non_blocking=True)
+                if d2h_bytes:
+                    with torch.cuda.stream(s2):
+                        hd.copy_(dd, non_blocking=True)
+            torch.cuda.synchronize()
+            best = (time.perf_counter() - t0) / reps
+        return best
+    big = 256 << 20
+    peak_h2d = big / copy_time(big, 0, 8) / 1e9
+    peak_d2h = big / copy_time(0, big, 8) / 1e9
+    t_bidir = copy_time(big, big, 8)
+    t_copy = copy_time(up_bytes, down_bytes, max(4, min(64, int(0.2 / max(t_pipe, 1e-4)))))
+    bound = max(t_copy, t_compute)
+    return {"frames_per_slot": F, "slots": slots, "passes_timed": passes, "input": "RGB8" if rgb else "gray",
+            "source": ("pageable host memory, copied into the pinned slot by the submitting thread (orbfe_ingest_submit_from, what the "
+                       "driver does behind the reference's cudaMemcpy2DAsync)" if pageable else
+                       "pinned slots filled in place by the producer (orbfe_ingest_host_frames)"),
+            "value": kp / (t_pipe * passes), "unit": "keypoints/s", "frames_per_s": F / t_pipe,
+            "ms_per_slot": {"pipelined": t_pipe * 1e3, "copy_alone_both_directions": t_copy * 1e3, "compute_alone": t_compute * 1e3,
+                            "in_pipeline_upload": up_ms, "in_pipeline_compute": cmp_ms, "in_pipeline_download": down_ms},
+            "bytes_per_slot": {"upload": up_bytes, "download": down_bytes},
+            "h2d_GBps": {"achieved_pipelined": up_bytes / t_pipe / 1e9, "achieved_while_copying": up_bytes / (up_ms * 1e-3) / 1e9,
+                         "peak_measured_pinned": peak_h2d, "frac_of_peak": up_bytes / t_pipe / 1e9 / peak_h2d},
+            "d2h_GBps": {"achieved_pipelined": down_bytes / t_pipe / 1e9, "peak_measured_pinned": peak_d2h},
+            "bidirectional_GBps_measured_pinned": 2 * big / t_bidir / 1e9,
+            "overlap_efficiency": bound / t_pipe, "bound_by": "pcie_h2d" if t_copy >= t_compute else "compute",
+            "copy_over_compute": t_copy / t_compute,
+            "note": "same step as `value` of the headline but host -> device -> host; overlap_efficiency = max(copy alone, compute "
+                    "alone) / pipelined per slot; peaks are plain pinned hipMemcpyAsync of 256 MiB measured in this run"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -441,6 +570,10 @@ def main():
     ap.add_argument("--rgb", action="store_true",
                     help="feed interleaved RGB8 frames (SURVEY.md 8f-1): the gray conversion is fused into "
                          "the pyramid kernel; not the BASELINE metric (its configs are grayscale)")
+    ap.add_argument("--ingest", action="store_true",
+                    help="SURVEY.md 8f-1 staging: print ONE JSON line for the host -> device -> host pipeline (include/orbfe_ingest.h) "
+                         "at several slot sizes, gray and RGB8, pinned and pageable sources; 1 GPU.  The default line carries the "
+                         "1024-frame gray figure as the key `ingest`")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the keypoint gather out of the timed region")
     ap.add_argument("--exact-gather", action="store_true", help="N > 1: variable-length gather (counts first, then exactly "
                                                                   "sum(counts) * 52 bytes per rank)")
@@ -529,6 +662,33 @@ def main():
         if world != 1:
             sys.exit("bench.py: --mode align is a single-GPU bench (frames are independent: N GPUs = N replicas)")
         align_bench(args, torch, np, orbfe, dev, json_out)
+        return
+    if args.ingest:
+        if world != 1:
+            sys.exit("bench.py: --ingest is a single-GPU bench (every GPU has its own PCIe link: N GPUs = N replicas)")
+        mode = args.mode if args.mode in ("c2", "ref") else "c2"  # the ring matches f - 1 -> f inside a slot, as these modes do
+        runs = []
+        for F, rgb, pageable in ((256, False, False), (1024, False, False), (4096, False, False), (1024, True, False),
+                                 (1024, False, True)):
+            F = min(F, args.batch) if args.batch else F
+            runs.append(ingest_bench(torch, np, orbfe, synth, dev, mode, args.scene, F, passes=max(args.steps, 12) if F < 4096 else 9,
+                                     rgb=rgb, pageable=pageable))
+        head = next(r for r in runs if r["frames_per_slot"] == (min(1024, args.batch) if args.batch else 1024) and r["input"] == "gray"
+                    and r["source"].startswith("pinned"))
+        mm_ = MODES[mode]
+        line = {"metric": "ORB keypoints/sec end-to-end INCLUDING PCIe (pinned host frames in, host records out), %dx%d" % (mm_["width"], mm_["height"]),
+                "value": head["value"], "unit": "keypoints/s", "n_gpus": 1, "steps": head["passes_timed"], "warmup": 3,
+                "ms_per_step": head["ms_per_slot"]["pipelined"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "u8", "data": "synthetic",
+                "config": {"workload": mm_["workload"] + " -- staged through include/orbfe_ingest.h", "mode": mode, "ingest": True,
+                           "frames_per_gpu_per_step": head["frames_per_slot"]},
+                "roofline": {"bound": "pcie", "achieved": head["h2d_GBps"]["achieved_pipelined"], "peak": head["h2d_GBps"]["peak_measured_pinned"],
+                             "unit": "GB/s", "frac": head["h2d_GBps"]["frac_of_peak"], "traffic": None,
+                             "note": "this line is bound by the host link, not by HBM: achieved = uploaded bytes / pipelined time, peak = "
+                                     "pinned hipMemcpyAsync H2D measured in the same run; the device-resident HBM roofline is the default line's"},
+                "overlap_efficiency": head["overlap_efficiency"], "bound_by": head["bound_by"], "runs": runs, "cpu_baseline": None}
+        json_out.write(json.dumps(line) + "\n")
+        json_out.flush()
         return
     m = MODES[args.mode]
     w, h = m["width"], m["height"]
@@ -707,6 +867,12 @@ def main():
                                     "frames_per_s": r3["frames_total"] * args.steps / r3["elapsed"],
                                     "keypoints_per_frame": r3["kp_total"] / max(r3["frames_total"], 1)}
         del frames2
+        if world == 1 and args.mode in ("c2", "ref") and not args.rgb:
+            # f1's staging half: the same step with the frames starting in pinned host memory and the results ending there
+            try:
+                extras["ingest"] = ingest_bench(torch, np, orbfe, synth, dev, args.mode, args.scene, min(1024, max(B, 2)), passes=12)
+            except Exception as e:  # never lose the headline over the extra
+                extras["ingest"] = {"error": str(e)}
         if args.mode == "c2" and world == 1:
             # The corrected EXT modes on the same step.  The headline is the reference's quirk-parity
             # regime: orientation in radians used as degrees (Q7), description always on level 0 (Q10).  The 222-break

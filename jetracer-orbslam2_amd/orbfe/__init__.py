@@ -171,6 +171,34 @@ _POSE_SIGS = {  # include/orbfe_pose.h: f4, host code inside liborbfe.so
 }
 POSE_EXPORTS = tuple(_POSE_SIGS)
 
+
+class IngestConfig(C.Structure):  # orbfe_ingest_config, include/orbfe_ingest.h
+    _fields_ = [("slots", C.c_int32), ("frames_per_slot", C.c_int32), ("channels", C.c_int32), ("match_mode", C.c_int32),
+                ("match_window", C.c_int32), ("match_max_distance", C.c_int32), ("download_matches", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+_INGEST_SIGS = {  # include/orbfe_ingest.h: the pinned host <-> device staging ring (host code inside liborbfe.so)
+    "orbfe_ingest_default_config": (None, [C.POINTER(IngestConfig), C.c_int]),
+    "orbfe_ingest_create": (C.c_int, [C.c_void_p, C.POINTER(IngestConfig), C.POINTER(C.c_void_p)]),
+    "orbfe_ingest_destroy": (None, [C.c_void_p]),
+    "orbfe_ingest_last_error": (C.c_char_p, [C.c_void_p]),
+    "orbfe_ingest_slots": (C.c_int, [C.c_void_p]),
+    "orbfe_ingest_frame_bytes": (C.c_size_t, [C.c_void_p]),
+    "orbfe_ingest_host_frames": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "orbfe_ingest_submit": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "orbfe_ingest_submit_from": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t]),
+    "orbfe_ingest_ready": (C.c_int, [C.c_void_p, C.c_int]),
+    "orbfe_ingest_wait": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                    C.POINTER(C.c_void_p)]),
+    "orbfe_ingest_device_buffers": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                              C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "orbfe_ingest_compute_stream": (C.c_void_p, [C.c_void_p]),
+    "orbfe_ingest_timing": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                      C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+}
+INGEST_EXPORTS = tuple(_INGEST_SIGS)
+
 _lib = None
 
 
@@ -199,7 +227,7 @@ def lib():
                                  "`make -C jetracer-orbslam2_amd/csrc` (needs hipcc; there is "
                                  "no CPU fallback)" % LIB_PATH)
         L = C.CDLL(LIB_PATH)
-        for name, (res, args) in list(_SIGS.items()) + list(_WIRE_SIGS.items()) + list(_POSE_SIGS.items()):
+        for name, (res, args) in list(_SIGS.items()) + list(_WIRE_SIGS.items()) + list(_POSE_SIGS.items()) + list(_INGEST_SIGS.items()):
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
@@ -321,3 +349,96 @@ class Context:
         buf = np.empty((h, pitch), np.uint8)
         check(lib().orbfe_memcpy_d2h(buf.ctypes.data, ptr + frame * fs, h * pitch, stream))
         return buf[:, :w].copy()
+
+
+def _host_array(ptr, dtype, count):
+    """numpy view (no copy) of `count` elements of pinned host memory the library owns."""
+    dt = np.dtype(dtype)
+    buf = (C.c_uint8 * (count * dt.itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dt, count=count)
+
+
+class Ingest:
+    """orbfe_ingest (include/orbfe_ingest.h): a ring of pinned host slots around Context.extract (+ match_batch); upload of
+    slot s + 1 and download of slot s - 1 overlap the extraction of slot s.  Host arrays are views of the library's pinned
+    buffers, not copies."""
+
+    def __init__(self, ctx, frames_per_slot, slots=3, channels=1, match_mode=-1, match_window=-1, match_max_distance=256,
+                 download_matches=0):
+        self.ctx = ctx  # keeps the context alive
+        self.cfg = IngestConfig(slots, frames_per_slot, channels, match_mode, match_window, match_max_distance,
+                                download_matches, 0)
+        h = C.c_void_p()
+        code = lib().orbfe_ingest_create(ctx.handle, C.byref(self.cfg), C.byref(h))
+        if code != OK:
+            msg = lib().orbfe_ingest_last_error(None)
+            raise OrbfeError(code, msg.decode() if msg else "")
+        self.handle = h
+        self.slots = slots
+        self.frames_per_slot = frames_per_slot
+        self.frame_bytes = lib().orbfe_ingest_frame_bytes(h)
+        self.shape = (ctx.cfg.height, ctx.cfg.width) + ((3,) if channels == 3 else ())
+
+    def _check(self, code):
+        if code != OK:
+            msg = lib().orbfe_ingest_last_error(self.handle)
+            raise OrbfeError(code, msg.decode() if msg else "")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().orbfe_ingest_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def host_frames(self, slot):
+        """[frames_per_slot, H, W(, 3)] u8 view of the slot's pinned input buffer."""
+        p = lib().orbfe_ingest_host_frames(self.handle, slot)
+        if not p:
+            raise OrbfeError(ERR_INVALID_ARG, "no such slot")
+        return _host_array(p, np.uint8, self.frames_per_slot * self.frame_bytes).reshape((self.frames_per_slot,) + self.shape)
+
+    def submit(self, slot, n_frames):
+        self._check(lib().orbfe_ingest_submit(self.handle, slot, n_frames))
+
+    def submit_from(self, slot, frames):
+        """frames: C-contiguous numpy [n, H, W(, 3)] u8 in ordinary (pageable) memory."""
+        a = np.ascontiguousarray(frames, dtype=np.uint8)
+        n = a.shape[0]
+        row = self.shape[1] * (3 if len(self.shape) == 3 else 1)
+        self._check(lib().orbfe_ingest_submit_from(self.handle, slot, n, a.ctypes.data, row, self.frame_bytes))
+
+    def ready(self, slot):
+        return bool(lib().orbfe_ingest_ready(self.handle, slot))
+
+    def wait(self, slot, n_frames=None):
+        """(records [n, cap], counts [n], match_idx or None, match_dist or None) as views of the slot's pinned result buffers."""
+        r, c, i, d = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._check(lib().orbfe_ingest_wait(self.handle, slot, C.byref(r), C.byref(c), C.byref(i), C.byref(d)))
+        n = self.frames_per_slot if n_frames is None else n_frames
+        cap = self.ctx.cap
+        rec = _host_array(r.value, KEYPOINT_DTYPE, n * cap).reshape(n, cap)
+        cnt = _host_array(c.value, np.int32, n)
+        idx = _host_array(i.value, np.int32, max(n - 1, 0) * cap).reshape(max(n - 1, 0), cap) if i.value else None
+        dst = _host_array(d.value, np.int32, max(n - 1, 0) * cap).reshape(max(n - 1, 0), cap) if d.value else None
+        return rec, cnt, idx, dst
+
+    def device_buffers(self, slot):
+        p = [C.c_void_p() for _ in range(5)]
+        self._check(lib().orbfe_ingest_device_buffers(self.handle, slot, *[C.byref(x) for x in p]))
+        return tuple(x.value or 0 for x in p)
+
+    def compute_stream(self):
+        return lib().orbfe_ingest_compute_stream(self.handle) or 0
+
+    def timing(self, slot):
+        """{'upload_ms', 'compute_ms', 'download_ms', 'upload_bytes', 'download_bytes'} of the slot's last completed pass."""
+        t = [C.c_float() for _ in range(3)]
+        b = [C.c_size_t() for _ in range(2)]
+        self._check(lib().orbfe_ingest_timing(self.handle, slot, *[C.byref(x) for x in t + b]))
+        return dict(upload_ms=t[0].value, compute_ms=t[1].value, download_ms=t[2].value, upload_bytes=b[0].value,
+                    download_bytes=b[1].value)

@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "orbfe.h")).read()
+def declared_symbols(header="orbfe.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(orbfe_[a-z0-9_]+)\s*\(", text)))
 
@@ -32,6 +32,28 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert lib.orbfe_version() == 2
     assert lib.orbfe_load_pattern() == orbfe.OK
+
+
+def test_ingest_header_is_bound_and_exported():
+    """include/orbfe_ingest.h (the staging ring): every declared symbol is bound and exported, the config
+    struct is 8 x int32, and the entry points refuse bad arguments before any HIP call."""
+    import orbfe
+    assert sorted(orbfe.INGEST_EXPORTS) == declared_symbols("orbfe_ingest.h")
+    lib = orbfe.lib()
+    for name in orbfe.INGEST_EXPORTS:
+        assert hasattr(lib, name), name
+    assert C.sizeof(orbfe.IngestConfig) == 32
+    cfg = orbfe.IngestConfig()
+    lib.orbfe_ingest_default_config(C.byref(cfg), 64)
+    assert (cfg.slots, cfg.frames_per_slot, cfg.channels, cfg.match_mode, cfg.download_matches) == (3, 64, 1, -1, 0)
+    h = C.c_void_p()
+    assert lib.orbfe_ingest_create(None, C.byref(cfg), C.byref(h)) == orbfe.ERR_INVALID_ARG
+    assert b"orbfe_ingest_create" in lib.orbfe_ingest_last_error(None)
+    assert lib.orbfe_ingest_submit(None, 0, 1) == orbfe.ERR_INVALID_ARG
+    assert lib.orbfe_ingest_wait(None, 0, None, None, None, None) == orbfe.ERR_INVALID_ARG
+    assert lib.orbfe_ingest_slots(None) == 0 and lib.orbfe_ingest_frame_bytes(None) == 0
+    assert not lib.orbfe_ingest_host_frames(None, 0)
+    lib.orbfe_ingest_destroy(None)
 
 
 def test_struct_layouts_match_the_header():
