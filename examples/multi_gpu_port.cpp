@@ -8,7 +8,11 @@
 //              orbfe_dist_gather_keypoints(... root 0 ...)   // RCCL over xGMI, keypoint records only
 //   rank 0 then holds every frame's records in frame order and writes them to <out.bin>.
 //
-//   multi_gpu_port <n_gpus> <width> <height> <n_frames> <frames_u8.bin> <out.bin> [exact]
+//   multi_gpu_port <n_gpus> <width> <height> <n_frames> <frames_u8.bin> <out.bin> [exact] [devices=a,b,...]
+//
+// devices= picks the HIP device of every rank (default: rank r on device r).  Naming one device twice is what RCCL itself
+// refuses ("Duplicate GPU detected"); tests/test_gpu_round5.py does it on a one-GPU box with a loopback transport in
+// place of librccl.so.1 to execute the world > 1 branches of liborbfe_dist.so.
 //
 // out = [int32 n_frames | int32 cap | int32 counts[n_frames] | records n_frames * cap * 52 bytes] (fixed stride)
 // tests/test_gpu_round2.py::test_cpp_multi_gpu_port runs it with one GPU and compares with the oracle; on a
@@ -52,6 +56,7 @@
 
 struct Job {
     int world, width, height, n_frames, exact;
+    std::vector<int> devices;   // HIP device of rank r
     const uint8_t *frames;      // host, n_frames * width * height
     uint8_t id[ORBFE_DIST_ID_BYTES];
     std::vector<int32_t> counts; // filled by rank 0
@@ -62,7 +67,8 @@ struct Job {
 static void rank_main(Job *job, int rank)
 {
     const int w = job->width, h = job->height;
-    CHECK_HIP(hipSetDevice(rank));
+    const int device = job->devices[rank];
+    CHECK_HIP(hipSetDevice(device));
     hipStream_t stream;
     CHECK_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     int f0, f1;
@@ -75,12 +81,12 @@ static void rank_main(Job *job, int rank)
     cfg.min_arc = 9;
     cfg.max_features = 2000;
     cfg.max_batch = n;
-    cfg.device = rank;
+    cfg.device = device;
     orbfe_ctx *ctx = nullptr;
     CHECK_ORBFE(orbfe_create(&cfg, &ctx), nullptr);
     const int cap = orbfe_max_keypoints(ctx);
     orbfe_dist *dist = nullptr;
-    CHECK_DIST(orbfe_dist_create(job->id, rank, job->world, rank, &dist), nullptr);
+    CHECK_DIST(orbfe_dist_create(job->id, rank, job->world, device, &dist), nullptr);
 
     uint8_t *d_gray;
     orbfe_keypoint *d_records, *d_all_records = nullptr;
@@ -141,10 +147,23 @@ int main(int argc, char **argv)
     job.width = std::atoi(argv[2]);
     job.height = std::atoi(argv[3]);
     job.n_frames = std::atoi(argv[4]);
-    job.exact = argc > 7 && !std::strcmp(argv[7], "exact");
+    job.exact = 0;
+    for (int a = 7; a < argc; a++) {
+        if (!std::strcmp(argv[a], "exact")) job.exact = 1;
+        if (!std::strncmp(argv[a], "devices=", 8))
+            for (const char *p = argv[a] + 8; *p;) {
+                job.devices.push_back(std::atoi(p));
+                while (*p && *p != ',') p++;
+                if (*p == ',') p++;
+            }
+    }
     const int ndev = orbfe_device_count();
-    if (job.world < 1 || job.world > ndev || job.n_frames % job.world != 0) {
-        std::fprintf(stderr, "need 1 <= n_gpus <= %d and n_frames %% n_gpus == 0\n", ndev);
+    if (job.devices.empty())
+        for (int r = 0; r < job.world; r++) job.devices.push_back(r);
+    bool devices_ok = (int)job.devices.size() == job.world;
+    for (int dv : job.devices) devices_ok = devices_ok && dv >= 0 && dv < ndev;
+    if (job.world < 1 || !devices_ok || job.n_frames % job.world != 0) {
+        std::fprintf(stderr, "need n_gpus >= 1 ranks on devices 0..%d (one per rank) and n_frames %% n_gpus == 0\n", ndev - 1);
         return 1;
     }
     std::vector<uint8_t> frames((size_t)job.width * job.height * job.n_frames);

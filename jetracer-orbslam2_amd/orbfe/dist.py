@@ -15,8 +15,9 @@ Two implementations of the same exchange:
 import ctypes as C
 import os
 
-import torch
-import torch.distributed as dist
+# torch is imported only by the torch.distributed rehearsal functions below: RcclComm and dist_lib() are ctypes over
+# liborbfe_dist.so and must stay usable in a process that never loads torch (tests/fake_rccl/world2_worker.py runs the
+# library's world > 1 branches against a loopback transport and must not have torch's own librccl in the process)
 
 DIST_LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "liborbfe_dist.so")
 DIST_ID_BYTES = 128
@@ -155,6 +156,8 @@ def gather_keypoints_async(records, counts, out=None, dst=0, group=None):
     """Like gather_keypoints but returns at once (async_op=True): the collective is ordered
     after the work already queued on the current stream and overlaps what is queued next
     (the following step's kernels).  `out` = (records_all, counts_all) buffers to reuse on dst."""
+    import torch
+    import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return AsyncGather([], records.unsqueeze(0), counts.unsqueeze(0))
     world = dist.get_world_size(group)
@@ -178,6 +181,8 @@ def gather_keypoints(records, counts, dst=0, group=None):
     Returns (records_all [world, ...], counts_all [world, frames_local]) on dst, (None, None)
     elsewhere.  Without an initialised process group (single process) it is the identity.
     """
+    import torch
+    import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return records.unsqueeze(0), counts.unsqueeze(0)
     world = dist.get_world_size(group)
@@ -197,6 +202,8 @@ def merge_cell_keys(keys, group=None):
     """All-reduce(MAX) of per-cell detection keys across ranks (tile-sharded detection of one
     large frame, orbfe_detect_batch_shard).  keys: int32 tensor viewing the uint32 keys (all
     < 2**27, so signed MAX == unsigned MAX).  In place; identity without a process group."""
+    import torch
+    import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(keys, op=dist.ReduceOp.MAX, group=group)
     return keys

@@ -2,9 +2,16 @@
   * f1, the staging half (include/orbfe_ingest.h; buildStream.cpp:376-381, :399-406, :462-466, :483-487): frames that go
     host (pinned ring) -> device -> orbfe_extract / orbfe_extract_rgb (+ orbfe_match_batch) -> host must give the records
     the device-resident entry points give and the oracle gives, through ring wrap-around, partial slots, pageable
-    sources with a pitch, and the slot state machine's refusals.
+    sources with a pitch, and the slot state machine's refusals;
+  * 8e, the branches of liborbfe_dist.so under `world > 1` (grouped ncclSend / ncclRecv, root placement, exact-length
+    packing, the all-reduce), executed on ONE GPU by 2 and 3 ranks over a test-only loopback transport that stands in for
+    librccl.so.1 (tests/fake_rccl): worker processes without torch, and examples/multi_gpu_port with both threads on device 0.
 The oracle is unpinned by the reference (it holds no tests); see oracle/orbfe_oracle.h."""
 import ctypes as C
+import json
+import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -184,3 +191,119 @@ def test_ingest_slot_state_machine(gpu):
     ing.wait(0, 1)
     ing.close()
     ctx.close()
+
+
+# ------------------------------------------------------------------ 8e: world > 1 over the loopback transport
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAKE_DIR = os.path.join(ROOT, "tests", "fake_rccl")
+
+
+def _loopback_env():
+    """Environment of a child whose liborbfe_dist.so resolves librccl.so.1 to the loopback transport (built on demand;
+    __graft_entry__.build() builds it too).  The product library is the shipped one: only the loader's search path changes."""
+    out = os.path.join(FAKE_DIR, "_build", "librccl.so.1")
+    src = os.path.join(FAKE_DIR, "fake_rccl.cpp")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", FAKE_DIR])
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.join(FAKE_DIR, "_build") + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    return env
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_dist_world_gt1_over_the_loopback_transport(gpu, oracle_mod, tmp_path, world):
+    """`world` worker processes (tests/fake_rccl/world2_worker.py), all on device 0, drive every entry point of
+    include/orbfe_dist.h whose body sits under `world > 1`; what the root received must be the oracle's records in frame
+    order: fixed stride (root extracting in place), exact length (+ the offset table), a non-zero root, the C5
+    all-reduce(MAX) flow on every rank, and the host reductions."""
+    torch, orbfe = gpu
+    sys.path.insert(0, FAKE_DIR)
+    import world2_worker as ww
+    env = _loopback_env()
+    scratch = str(tmp_path)
+    procs = [subprocess.Popen([sys.executable, os.path.join(FAKE_DIR, "world2_worker.py"), str(r), str(world), scratch], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o.decode(errors="replace"))
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o)
+    n_total, n = ww.N_TOTAL, ww.N_TOTAL // world
+    ocfg = oracle_mod.make_config(ww.W, ww.H, **ww.CFG)
+    refs = [oracle_mod.extract_frame(ww.scene(i), ocfg) for i in range(n_total)]
+    ref_counts = np.array([r["count"] for r in refs], np.int32)
+    assert ref_counts.min() < 200 < ref_counts.max(), "ragged counts: the exact form must ship fewer bytes than the fixed one"
+    for name in ("fixed", "root1"):
+        z = np.load(os.path.join(scratch, name + ".npz"))
+        cap = int(z["cap"])
+        rec = z["records"].view(orbfe.KEYPOINT_DTYPE).reshape(n_total, cap)
+        np.testing.assert_array_equal(z["counts"], ref_counts)
+        for f in range(n_total):
+            assert rec[f, :ref_counts[f]].tobytes() == refs[f]["records"].tobytes(), (name, f)
+    z = np.load(os.path.join(scratch, "exact.npz"))
+    cap = int(z["cap"])
+    np.testing.assert_array_equal(z["counts"], ref_counts)
+    rec = z["records"].view(orbfe.KEYPOINT_DTYPE)
+    want_off = np.array([(f // n) * n * cap + ref_counts[(f // n) * n:f].sum() for f in range(n_total)], np.int64)
+    np.testing.assert_array_equal(z["offsets"], want_off)
+    for f in range(n_total):
+        got = rec[want_off[f]:want_off[f] + ref_counts[f]]
+        assert got.tobytes() == refs[f]["records"].tobytes(), ("exact", f)
+    for r in range(1, world):  # the bytes behind a rank's dense block were never shipped: still the root's fill pattern
+        used = int(ref_counts[r * n:(r + 1) * n].sum())
+        tail = z["records"][52 * (r * n * cap + used):52 * (r + 1) * n * cap]
+        assert tail.size > 0 and (tail == 0xEE).all()
+    # C5: every rank ends with the full frame's records; the partial keys differ per rank and their maximum is the merge
+    o5 = oracle_mod.make_config(ww.C5["width"], ww.C5["height"], **ww.C5["cfg"])
+    ref5 = oracle_mod.extract_frame(ww.c5_scene(), o5)
+    parts = []
+    for r in range(world):
+        z = np.load(os.path.join(scratch, "c5_%d.npz" % r))
+        assert int(z["count"][0]) == ref5["count"] > 300
+        got = z["records"].view(orbfe.KEYPOINT_DTYPE)[:ref5["count"]]
+        assert got.tobytes() == ref5["records"].tobytes(), "rank %d" % r
+        parts.append(z["partial_keys"])
+        np.testing.assert_array_equal(z["merged_keys"], np.load(os.path.join(scratch, "c5_0.npz"))["merged_keys"])
+    assert all((parts[0] != parts[r]).any() for r in range(1, world)), "the shards saw different tiles"
+    np.testing.assert_array_equal(np.maximum.reduce(parts), np.load(os.path.join(scratch, "c5_0.npz"))["merged_keys"])
+    for r in range(world):
+        hst = json.load(open(os.path.join(scratch, "host_%d.json" % r)))
+        assert hst["max"] == [float(world), 10.0 * (world - 1), -3.5]
+        assert hst["sum"] == [world * (world + 1) / 2.0, 10.0 * world * (world - 1) / 2.0, -3.5 * world]
+        assert all("fake_rccl/_build" in p for p in hst["librccl"])
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_cpp_multi_gpu_port_two_ranks_on_one_device(gpu, oracle_mod, tmp_path, exact):
+    """examples/multi_gpu_port (the reference's thread-per-stream model, one C++ thread + context + communicator rank per
+    GPU) with TWO ranks, both on device 0 (`devices=0,0`), over the loopback transport: rank 0's gathered file must be the
+    oracle's records frame by frame.  With real RCCL the same command needs two GPUs."""
+    torch, orbfe = gpu
+    exe = os.path.join(ROOT, "examples", "multi_gpu_port")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    w, h, n = 640, 480, 6
+    frames = np.stack([synth.frame(w, h, 160 + i, "rects", n_rects=96 if i % 2 else 800, min_size=6, max_size=None if i % 2 else 32)
+                       for i in range(n)])
+    fin, fout = str(tmp_path / "frames.bin"), str(tmp_path / "out.bin")
+    frames.tofile(fin)
+    cmd = [exe, "2", str(w), str(h), str(n), fin, fout] + (["exact"] if exact else []) + ["devices=0,0"]
+    r = subprocess.run(cmd, env=_loopback_env(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")
+    assert b"2 GPU(s)" in r.stdout
+    raw = np.fromfile(fout, np.uint8)
+    nf, cap = raw[:8].view(np.int32)
+    assert nf == n and cap == 2000
+    counts = raw[8:8 + 4 * n].view(np.int32)
+    rec = raw[8 + 4 * n:].view(orbfe.KEYPOINT_DTYPE).reshape(n, cap)
+    ocfg = oracle_mod.make_config(w, h, levels=8, cell=8, min_arc=9, max_features=2000)
+    for f in range(n):
+        ref = oracle_mod.extract_frame(frames[f], ocfg)
+        assert counts[f] == ref["count"]
+        assert rec[f, :counts[f]].tobytes() == ref["records"].tobytes()
