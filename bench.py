@@ -453,11 +453,13 @@ def ingest_bench(torch, np, orbfe, synth, dev, mode, scene, frames_per_slot, pas
         else:
             ing.submit(sl, F)
 
-    # warm-up: every slot once (first-touch of the pinned pages, clocks)
-    for sl in range(slots):
-        submit(sl)
-    for sl in range(slots):
-        ing.wait(sl)
+    # warm-up: three rounds through the ring (first touch of the pinned pages, the runtime's signal / staging pools, clocks:
+    # tools/ingest_probe.py shows the first configuration of a process spending 0.3 ms per submit on the host, 0.06 later)
+    for _ in range(3):
+        for sl in range(slots):
+            submit(sl)
+        for sl in range(slots):
+            ing.wait(sl)
     t_first = ing.timing(0)
     up_bytes, down_bytes = t_first["upload_bytes"], t_first["download_bytes"]
     # pipelined: `passes` slot passes through the ring, the host only submits and waits

@@ -60,8 +60,10 @@ typedef struct orbfe_pyramid_level {
     float *response;
 } orbfe_pyramid_level;
 
-/* enum fast_score, src/cuda/fast.cuh:18-23.  Only SUM_OF_ABS_DIFF_ON_ARC is on the live
- * path (src/SlamGpuPipeline/defines.h:9); the others return ORBFE_ERR_UNSUPPORTED. */
+/* enum fast_score, src/cuda/fast.cuh:18-23: what orbfe_fast_calc_corner_response writes for an accepted pixel --
+ * the sum of |p - c| over the ring (fast.cu:233-241), the larger of the two sums of |p - c| - t over the darker /
+ * brighter ring pixels (:243-255; the live path's, src/SlamGpuPipeline/defines.h:9, and the only one orbfe_detect and
+ * the batch API use), or the largest threshold at which the table still accepts the pixel (:256-283). */
 enum {
     ORBFE_SUM_OF_ABS_DIFF_ALL = 0,
     ORBFE_SUM_OF_ABS_DIFF_ON_ARC = 1,
@@ -167,8 +169,8 @@ typedef struct orbfe_intrinsics {
 
 /* keypoint_pixel_to_point, src/cuda/cuda-align.cuh (kernel cuda-align.cu:282-364), SURVEY.md 8f-2,
  * the step right after the path: keep keypoints with aligned depth > 1 and score > 1, compact
- * them and deproject to 3-D (3 doubles per point).  Differences: `intrin` is a HOST pointer (read
- * at call time); the compacted order is by keypoint index (the reference's atomics give an
+ * them and deproject to 3-D (3 doubles per point).  Differences: `intrin` may be a HOST pointer (read
+ * at call time) or, as in the reference, a DEVICE pointer (copied back once per call); the compacted order is by keypoint index (the reference's atomics give an
  * arbitrary order); *d_valid_keypoints_num is written by the kernel, nothing is copied to the host.
  * fix_depth_index = 0 reproduces the reference's depth lookup depth[int(y+.5) * W + int(y+.5)]
  * (it uses y for the column, cuda-align.cu:332; needs height <= width); 1 uses int(x+.5).
@@ -192,15 +194,17 @@ typedef struct orbfe_extrinsics {
  * orbfe_keypoint_pixel_to_point reads (buildStream.cpp:385, :468).  Every depth pixel with depth != 0 is mapped
  * twice (corners -0.5 and +0.5: deproject, transform, project, int(v + 0.5f)), and its raw 16-bit depth goes by
  * minimum into every output pixel of the rectangle between the two images; pixels no rectangle covers read 0.
- * Same arguments as the reference, with these differences: the three camera structs are HOST pointers read at
- * call time (the reference passes device copies); d_pixel_map, the reference's int2[2 W H] scratch, is not
+ * Same arguments as the reference, with these differences: the three camera structs may be HOST pointers read at
+ * call time or the reference's DEVICE copies (_d_depth_intrinsics ..., SlamGpuPipeline.cpp:53-55: detected with
+ * hipPointerGetAttributes and copied back with one small synchronous hipMemcpy per call); d_pixel_map, the reference's int2[2 W H] scratch, is not
  * touched and may be NULL (map and splat are one kernel; nothing else ever read the map); depth_scale must be
  * finite.  As in the reference the launch grid is made from image_width / image_height (32 x 32 blocks) while
  * all bounds come from the intrinsics: depth pixels / output pixels beyond the grid are not read / not reset.
  * d_depth_in: depth_intrin->width * height uint16, d_aligned_out: other_intrin->width * height uint32, both
- * contiguous.  Depth model 1 / 3 (the reference asserts) and other model 3 (f-theta: double atan / tan from
- * libdevice) return ORBFE_ERR_UNSUPPORTED.  Float arithmetic as written, no contraction: parity with the
- * reference unpinned at the ulp level, bit-exact against the oracle. */
+ * contiguous.  Depth model 1 / 3 (the reference asserts) returns ORBFE_ERR_UNSUPPORTED; other model 3 (f-theta,
+ * cuda-align.cu:44-50) is evaluated in float with the build's deterministic atanf / tanf (orbfe_ftheta_distort,
+ * include/orbfe_math.h).  Float arithmetic as written, no contraction: parity with the reference unpinned at the ulp
+ * level, bit-exact against the oracle. */
 int orbfe_align_depth_to_other(uint32_t *d_aligned_out, const uint16_t *d_depth_in, void *d_pixel_map,
                                float depth_scale, int image_width, int image_height,
                                const orbfe_intrinsics *depth_intrin, const orbfe_intrinsics *other_intrin,
@@ -219,7 +223,7 @@ int orbfe_align_depth_batch(uint32_t *d_aligned_out, size_t out_frame_stride, co
  * column-major as Eigen::Matrix4d) and projected to pixels -- the positions orbfe_match_keypoints takes
  * as d_pos_prev.  Model 1 (modified Brown-Conrady) applies its polynomial; 0, 2 and 4 project
  * without distortion, exactly as the reference (its assert against model 2 is commented out, :15, and a D4xx colour
- * stream reports model 2); 3 (f-theta: libdevice's double atan / tan) returns ORBFE_ERR_UNSUPPORTED.  Parity unpinned at the ulp level (Eigen's
+ * stream reports model 2); 3 (f-theta, :32-38) as orbfe_ftheta_distort (include/orbfe_math.h).  `intrin` host or device pointer.  Parity unpinned at the ulp level (Eigen's
  * product order and nvcc's FMA contraction are not observable): ((T_i0 x + T_i1 y) + T_i2 z) + T_i3. */
 int orbfe_reproject_points(float *d_pos_out, const double *d_points_prev, int keypoints_num_prev,
                            const double *T_w2c_prev_curr, const orbfe_intrinsics *intrin, orbfe_stream_t stream);

@@ -137,6 +137,36 @@ ORBFE_HD void orbfe_sincosf(float xx, float *s_out, float *c_out)
     *c_out = c;
 }
 
+/* atan(x), any sign; tan(x) = sin / cos of orbfe_sincosf (one IEEE division), |x| < 8192. */
+ORBFE_HD float orbfe_atanf(float x) { return x < 0.0f ? -orbfe_atanf_nonneg(-x) : orbfe_atanf_nonneg(x); }
+ORBFE_HD float orbfe_tanf(float x)
+{
+    float s, c;
+    orbfe_sincosf(x, &s, &c);
+    return s / c;
+}
+
+/* The f-theta branch of librealsense's project_point_to_pixel as the reference compiles it
+ * (src/cuda/cuda-align.cu:44-50, src/cuda/post_processing.cu:32-38):
+ *     float r = sqrtf(x*x + y*y);
+ *     float rd = (float)(1.0f / coeffs[0] * atan(2 * r * tan(coeffs[0] / 2.0f)));
+ *     x *= rd / r;  y *= rd / r;
+ * Every operand is a float and the file is C++ (nvcc), so `tan` and `atan` resolve to the float overloads, i.e.
+ * libdevice's tanf / atanf: the whole expression is single precision.  Decision: the same operations in the same order
+ * with the build's own deterministic atanf / tanf above and a correctly rounded sqrtf; PARITY UNPINNED at the ulp
+ * level (libdevice's bits are not reproducible here), oracle == HIP bit for bit.  r == 0 gives 0 / 0 = NaN exactly as
+ * in the reference (the pixel then converts to 0 with cvt.rzi's NaN rule). */
+ORBFE_HD void orbfe_ftheta_distort(float *x, float *y, float c0)
+{
+    ORBFE_NO_CONTRACT
+    const float xx = *x, yy = *y;
+    const float r = __builtin_sqrtf(xx * xx + yy * yy);
+    const float t = orbfe_tanf(c0 / 2.0f);
+    const float rd = 1.0f / c0 * orbfe_atanf(2 * r * t);
+    *x = xx * (rd / r);
+    *y = yy * (rd / r);
+}
+
 /* Round to nearest, ties to even, then to int: the meaning of CUDA __float2int_rn
  * (src/cuda/orb.cu:13-14).  rintf under the default rounding mode; v_rndne_f32 on gfx950. */
 ORBFE_HD int orbfe_rn_int(float v) { return (int)__builtin_rintf(v); }

@@ -152,11 +152,14 @@ __device__ inline void to_other_point(const AlignArgs &A, float depth_val, float
     }
 }
 // (x, y) = other_point.xy / other_point.z -> the rounded pixel
-template <bool DO>
+// DO = the other camera's rs2_distortion as far as the projection cares: 0 none (models 0, 2, 4), 1 modified
+// Brown-Conrady, 3 f-theta
+template <int DO>
 __device__ inline void to_other_pixel(const AlignArgs &A, float x, float y, int *px, int *py)
 {
     ORBFE_NO_CONTRACT
-    if (DO) { // RS2_DISTORTION_MODIFIED_BROWN_CONRADY on the other camera
+    if (DO == 3) orbfe_ftheta_distort(&x, &y, A.o.coeffs[0]); // RS2_DISTORTION_FTHETA, cuda-align.cu:44-50
+    if (DO == 1) { // RS2_DISTORTION_MODIFIED_BROWN_CONRADY on the other camera
         const float *c = A.o.coeffs;
         const float r2 = x * x + y * y;
         float f = 1 + c[0] * r2;
@@ -218,7 +221,7 @@ __device__ inline int pk_x(uint32_t v) { return (int)(short)(v & 0xFFFFu); }
 __device__ inline int pk_y(uint32_t v) { return (int)v >> 16; }
 
 // VEC: depth rows are 8-byte aligned at every multiple of 4 pixels (width % 4 == 0, aligned base and frame stride)
-template <bool DD, bool DO, bool ZERO_INIT, bool VEC>
+template <bool DD, int DO, bool ZERO_INIT, bool VEC>
 __global__ void __launch_bounds__(256)
 align_splat_kernel(uint32_t *__restrict__ out, const uint16_t *__restrict__ depth, AlignArgs A)
 {
@@ -497,11 +500,14 @@ static inline hipStream_t S(orbfe_stream_t s) { return reinterpret_cast<hipStrea
 template <bool ZI, bool VEC>
 static void launch_splat(uint32_t *out, const uint16_t *depth, const AlignArgs &A, dim3 grid, hipStream_t s)
 {
-    const bool dd = A.d.model == 2, dO = A.o.model == 1;
-    if (dd && dO) hipLaunchKernelGGL((align_splat_kernel<true, true, ZI, VEC>), grid, dim3(256), 0, s, out, depth, A);
-    else if (dd) hipLaunchKernelGGL((align_splat_kernel<true, false, ZI, VEC>), grid, dim3(256), 0, s, out, depth, A);
-    else if (dO) hipLaunchKernelGGL((align_splat_kernel<false, true, ZI, VEC>), grid, dim3(256), 0, s, out, depth, A);
-    else hipLaunchKernelGGL((align_splat_kernel<false, false, ZI, VEC>), grid, dim3(256), 0, s, out, depth, A);
+    const bool dd = A.d.model == 2;
+    const int dO = A.o.model == 1 ? 1 : A.o.model == 3 ? 3 : 0;
+    if (dd && dO == 1) hipLaunchKernelGGL((align_splat_kernel<true, 1, ZI, VEC>), grid, dim3(256), 0, s, out, depth, A);
+    else if (dd && dO == 3) hipLaunchKernelGGL((align_splat_kernel<true, 3, ZI, VEC>), grid, dim3(256), 0, s, out, depth, A);
+    else if (dd) hipLaunchKernelGGL((align_splat_kernel<true, 0, ZI, VEC>), grid, dim3(256), 0, s, out, depth, A);
+    else if (dO == 1) hipLaunchKernelGGL((align_splat_kernel<false, 1, ZI, VEC>), grid, dim3(256), 0, s, out, depth, A);
+    else if (dO == 3) hipLaunchKernelGGL((align_splat_kernel<false, 3, ZI, VEC>), grid, dim3(256), 0, s, out, depth, A);
+    else hipLaunchKernelGGL((align_splat_kernel<false, 0, ZI, VEC>), grid, dim3(256), 0, s, out, depth, A);
 }
 
 // frames_per_launch: how many frames go through clear -> splat (-> close) together; the output of a chunk is cleared
@@ -514,11 +520,6 @@ static int align_frames(uint32_t *d_out, size_t out_stride, const uint16_t *d_de
     if (din->model == 1 || din->model == 3) {
         set_thread_error("%s: cannot deproject a forward-distorted depth image (model %d; the reference asserts, "
                          "cuda-align.cu:62-63)", what, din->model);
-        return ORBFE_ERR_UNSUPPORTED;
-    }
-    if (oin->model == 3) {
-        set_thread_error("%s: f-theta projection (cuda-align.cu:44-50) needs libdevice's double atan / tan: not reproducible",
-                         what);
         return ORBFE_ERR_UNSUPPORTED;
     }
     AlignArgs A;
@@ -617,6 +618,13 @@ int orbfe_align_depth_to_other(uint32_t *d_aligned_out, const uint16_t *d_depth_
 {
     (void)d_pixel_map; // the reference's int2 scratch (:382-396): never read by anyone else, not touched here
     ARG_CHECK(d_aligned_out && d_depth_in && depth_intrin && other_intrin && depth_to_other);
+    // the three camera structs: host pointers, or the reference's device copies (buildStream.cpp:391-393)
+    orbfe_intrinsics di_tmp, oi_tmp;
+    orbfe_extrinsics ex_tmp;
+    depth_intrin = host_view(depth_intrin, &di_tmp);
+    other_intrin = host_view(other_intrin, &oi_tmp);
+    depth_to_other = host_view(depth_to_other, &ex_tmp);
+    ARG_CHECK(depth_intrin && other_intrin && depth_to_other); // a device struct that could not be copied back
     ARG_CHECK(image_width > 0 && image_height > 0 && depth_intrin->width > 0 && depth_intrin->height > 0 &&
               other_intrin->width > 0 && other_intrin->height > 0);
     ARG_CHECK(other_intrin->width <= 32767 && other_intrin->height <= 32767); // output coordinates travel as int16 pairs
@@ -633,6 +641,12 @@ int orbfe_align_depth_batch(uint32_t *d_aligned_out, size_t out_frame_stride, co
 {
     ARG_CHECK(n_frames >= 0 && depth_intrin && other_intrin && depth_to_other);
     if (n_frames == 0) return ORBFE_OK;
+    orbfe_intrinsics di_tmp, oi_tmp;
+    orbfe_extrinsics ex_tmp;
+    depth_intrin = host_view(depth_intrin, &di_tmp);
+    other_intrin = host_view(other_intrin, &oi_tmp);
+    depth_to_other = host_view(depth_to_other, &ex_tmp);
+    ARG_CHECK(depth_intrin && other_intrin && depth_to_other);
     ARG_CHECK(d_aligned_out && d_depth_in);
     ARG_CHECK(depth_intrin->width > 0 && depth_intrin->height > 0 && other_intrin->width > 0 && other_intrin->height > 0);
     ARG_CHECK(other_intrin->width <= 32767 && other_intrin->height <= 32767);

@@ -200,6 +200,28 @@ struct DeviceScope {
     DeviceScope &operator=(const DeviceScope &) = delete;
 };
 
+// A small struct the caller hands over by pointer (rs2_intrinsics / rs2_extrinsics shaped): host memory is read in place;
+// DEVICE memory -- what the reference passes, _d_depth_intrinsics / _d_rgb_intrinsics / _d_depth_rgb_extrinsics of
+// SlamGpuPipeline.cpp:53-55, uploaded once -- is copied to `tmp` with one small synchronous hipMemcpy at call time (the
+// values travel to the kernels as launch arguments either way).  Returns the pointer to read, or nullptr when the copy
+// failed.  hipPointerGetAttributes fails for an ordinary host pointer (or says "unregistered"), which is the host case.
+template <typename T>
+inline const T *host_view(const T *p, T *tmp)
+{
+    if (!p) return nullptr;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError(); // not an error of ours: a plain host pointer
+        return p;
+    }
+    if (attr.type != hipMemoryTypeDevice) return p; // host, registered host, managed: readable here
+    if (hipMemcpy(tmp, p, sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return tmp;
+}
+
 } // namespace orbfe
 
 struct orbfe_ctx {

@@ -90,6 +90,9 @@ __global__ void fast_lut_kernel(uint8_t *__restrict__ lut, int min_arc)
 }
 
 // a5  corner response, float arithmetic as in fast.cu:150-287 (any float threshold)
+// SCORE = the reference's enum fast_score (fast.cuh:18-23): 0 SUM_OF_ABS_DIFF_ALL (fast.cu:233-241), 1 SUM_OF_ABS_DIFF_ON_ARC
+// (:243-255, the live one), 2 MAX_THRESHOLD (:256-283: bisection over the threshold with fast_gpu_is_corner_quick, :126-148)
+template <int SCORE>
 __global__ void fast_response_px_kernel(int w, int h, int pitch, const uint8_t *__restrict__ img,
                                         int hb, int vb, const uint8_t *__restrict__ lut,
                                         float threshold, int resp_pitch,
@@ -120,14 +123,40 @@ __global__ void fast_response_px_kernel(int w, int h, int pitch, const uint8_t *
                 bright |= (uint32_t)(ct < px[i]) << i;
             }
             if (lut[dark] | lut[bright]) {
-                float rb = 0.0f, rd = 0.0f;
+                if (SCORE == ORBFE_SUM_OF_ABS_DIFF_ALL) {
+                    float r = 0.0f;
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const float ad = fabsf(px[i] - c) - threshold;
-                    rd += (dark >> i & 1u) ? ad : 0.0f;
-                    rb += (bright >> i & 1u) ? ad : 0.0f;
+                    for (int i = 0; i < 16; i++) r += fabsf(px[i] - c);
+                    out = r;
+                } else if (SCORE == ORBFE_MAX_THRESHOLD) {
+                    // every value here is a multiple of 1/2 below 512 when the threshold is: exact in float whatever
+                    // the evaluation order, as in the oracle
+                    float min_thr = threshold + 1.0f, max_thr = 255.0f;
+                    while (min_thr <= max_thr) {
+                        const float med = floorf((min_thr + max_thr) * 0.5f);
+                        const float mt = c + med, m_t = c - med;
+                        uint32_t dk = 0, br = 0;
+#pragma unroll
+                        for (int i = 0; i < 16; i++) {
+                            dk |= (uint32_t)(px[i] < m_t) << i;
+                            br |= (uint32_t)(mt < px[i]) << i;
+                        }
+                        if (lut[dk] | lut[br])
+                            min_thr = med + 1.0f;
+                        else
+                            max_thr = med - 1.0f;
+                    }
+                    out = max_thr;
+                } else {
+                    float rb = 0.0f, rd = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const float ad = fabsf(px[i] - c) - threshold;
+                        rd += (dark >> i & 1u) ? ad : 0.0f;
+                        rb += (bright >> i & 1u) ? ad : 0.0f;
+                    }
+                    out = fmaxf(rb, rd);
                 }
-                out = fmaxf(rb, rd);
             }
         }
     }
@@ -365,6 +394,7 @@ __global__ void reproject_points_kernel(float *__restrict__ pos_out, const doubl
         x = dx;
         y = dy;
     }
+    if (K.model == 3) orbfe_ftheta_distort(&x, &y, K.coeffs[0]); // RS2_DISTORTION_FTHETA, post_processing.cu:32-38
     pos_out[2 * (size_t)idx] = x * K.fx + K.ppx;
     pos_out[2 * (size_t)idx + 1] = y * K.fy + K.ppy;
 }
@@ -577,14 +607,19 @@ int orbfe_fast_calc_corner_response(int w, int h, int pitch, const unsigned char
     (void)min_arc_length; // unused by the reference kernel too (fast.cu:160): the LUT decides
     ARG_CHECK(d_image && d_lut && d_response && w > 0 && h > 0 && pitch >= w &&
               resp_pitch_elems >= w && hb >= 3 && vb >= 3);
-    if (score != ORBFE_SUM_OF_ABS_DIFF_ON_ARC) {
-        set_thread_error("fast_calc_corner_response: only SUM_OF_ABS_DIFF_ON_ARC is on the "
-                         "reference's live path (defines.h:9)");
-        return ORBFE_ERR_UNSUPPORTED;
-    }
+    ARG_CHECK(score == ORBFE_SUM_OF_ABS_DIFF_ALL || score == ORBFE_SUM_OF_ABS_DIFF_ON_ARC || score == ORBFE_MAX_THRESHOLD);
+    ARG_CHECK(threshold - threshold == 0.0f); // finite: a NaN or infinite threshold would never end MAX_THRESHOLD's bisection
     dim3 block(64, 4), grid((w + 63) / 64, (h + 3) / 4);
-    hipLaunchKernelGGL(fast_response_px_kernel, grid, block, 0, S(stream), w, h, pitch, d_image, hb,
-                       vb, d_lut, threshold, resp_pitch_elems, d_response);
+    // fast.cu:325-384: one instantiation per score
+    if (score == ORBFE_SUM_OF_ABS_DIFF_ALL)
+        hipLaunchKernelGGL(fast_response_px_kernel<ORBFE_SUM_OF_ABS_DIFF_ALL>, grid, block, 0, S(stream), w, h, pitch, d_image, hb,
+                           vb, d_lut, threshold, resp_pitch_elems, d_response);
+    else if (score == ORBFE_MAX_THRESHOLD)
+        hipLaunchKernelGGL(fast_response_px_kernel<ORBFE_MAX_THRESHOLD>, grid, block, 0, S(stream), w, h, pitch, d_image, hb,
+                           vb, d_lut, threshold, resp_pitch_elems, d_response);
+    else
+        hipLaunchKernelGGL(fast_response_px_kernel<ORBFE_SUM_OF_ABS_DIFF_ON_ARC>, grid, block, 0, S(stream), w, h, pitch, d_image, hb,
+                           vb, d_lut, threshold, resp_pitch_elems, d_response);
     return launch_status("fast_calc_corner_response");
 }
 
@@ -708,13 +743,13 @@ int orbfe_reproject_points(float *d_pos_out, const double *d_points_prev, int n,
                            const orbfe_intrinsics *intrin, orbfe_stream_t stream)
 {
     ARG_CHECK(n >= 0 && T_w2c_prev_curr && intrin);
+    orbfe_intrinsics k_tmp; // host struct, or the reference's device copy (_d_rgb_intrinsics, post_processing.cuh:45)
+    intrin = host_view(intrin, &k_tmp);
+    ARG_CHECK(intrin);
     // model 2 (inverse Brown-Conrady, what a D4xx colour stream reports) and 4 project WITHOUT distortion in the
     // reference: its assert against model 2 is commented out (post_processing.cu:15) and only models 1 and 3 have a
-    // branch (:19-38).  Model 3 (f-theta) calls libdevice's double atan / tan: not reproducible, refused.
-    if (intrin->model == 3) {
-        set_thread_error("reproject_points: f-theta projection (post_processing.cu:32-38) needs libdevice's double atan / tan");
-        return ORBFE_ERR_UNSUPPORTED;
-    }
+    // branch (:19-38).  Model 3 (f-theta, :32-38) is orbfe_ftheta_distort: float atanf / tanf, the build's deterministic
+    // versions (include/orbfe_math.h).
     if (n == 0) return ORBFE_OK;
     ARG_CHECK(d_pos_out && d_points_prev);
     Mat4 T;
@@ -731,6 +766,9 @@ int orbfe_keypoint_pixel_to_point(const uint32_t *d_aligned_depth, const orbfe_i
                                   orbfe_stream_t stream)
 {
     ARG_CHECK(intrin && d_valid_keypoints_num && image_width > 0 && image_height > 0 && keypoints_num >= 0);
+    orbfe_intrinsics k_tmp; // host struct, or the reference's device copy (_d_rgb_intrinsics, buildStream.cpp:469)
+    intrin = host_view(intrin, &k_tmp);
+    ARG_CHECK(intrin);
     if (intrin->model == 1 || intrin->model == 3) {
         set_thread_error("keypoint_pixel_to_point: cannot deproject a forward-distorted image (model %d)",
                          intrin->model);

@@ -126,12 +126,13 @@ def fast_lut(min_arc):
     return lut
 
 
-def fast_response(img, lut, threshold=13.0, border=3):
+def fast_response(img, lut, threshold=13.0, border=3, score=1):
+    """score: the reference's enum fast_score (0 SUM_OF_ABS_DIFF_ALL, 1 SUM_OF_ABS_DIFF_ON_ARC, 2 MAX_THRESHOLD)."""
     img = np.ascontiguousarray(img, dtype=np.uint8)
     h, w = img.shape
     resp = np.full((h, w), -1.0, dtype=np.float32)
-    lib().oracle_fast_calc_corner_response(w, h, w, _p(img), border, border, _p(lut),
-                                           C.c_float(threshold), w, _p(resp))
+    lib().oracle_fast_calc_corner_response_score(w, h, w, _p(img), border, border, _p(lut),
+                                                 C.c_float(threshold), score, w, _p(resp))
     return resp
 
 

@@ -170,9 +170,31 @@ static int ring_offset(int i, int pitch)
 
 static int sgnbit(float v) { return signbit(v) ? 1 : 0; }
 
+/* fast_gpu_is_corner_quick, src/cuda/fast.cu:126-148: the labels re-made at another threshold */
+static int is_corner_quick(const uint8_t *lut, const float *px, float c, float threshold)
+{
+    const float ct = c + threshold;
+    const float c_t = c - threshold;
+    unsigned dark = 0, bright = 0;
+    for (int i = 0; i < 16; i++) {
+        dark += sgnbit(px[i] - c_t) ? (1u << i) : 0u;
+        bright += sgnbit(ct - px[i]) ? (1u << i) : 0u;
+    }
+    return lut[dark] || lut[bright];
+}
+
 void oracle_fast_calc_corner_response(int w, int h, int pitch, const uint8_t *img, int hb,
                                       int vb, const uint8_t *lut, float threshold,
                                       int resp_pitch_elems, float *resp)
+{
+    oracle_fast_calc_corner_response_score(w, h, pitch, img, hb, vb, lut, threshold, 1, resp_pitch_elems, resp);
+}
+
+/* the same with the reference's `score` argument (enum fast_score, fast.cuh:18-23): 0 SUM_OF_ABS_DIFF_ALL (:233-241),
+ * 1 SUM_OF_ABS_DIFF_ON_ARC (:243-255, the live one), 2 MAX_THRESHOLD (:256-283) */
+void oracle_fast_calc_corner_response_score(int w, int h, int pitch, const uint8_t *img, int hb,
+                                            int vb, const uint8_t *lut, float threshold, int score,
+                                            int resp_pitch_elems, float *resp)
 {
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
@@ -203,7 +225,23 @@ void oracle_fast_calc_corner_response(int w, int h, int pitch, const uint8_t *im
                 dark += sgnbit(px[i] - c_t) ? (1u << i) : 0u;
                 bright += sgnbit(ct - px[i]) ? (1u << i) : 0u;
             }
-            if (lut[dark] || lut[bright]) { /* :225 */
+            if ((lut[dark] || lut[bright]) && score == 0) { /* :233-241 */
+                float response = 0.0f;
+                for (int i = 0; i < 16; i++) response += fabsf(px[i] - c);
+                *out = response;
+            } else if ((lut[dark] || lut[bright]) && score == 2) { /* :256-283: the largest threshold at which the
+                                                                      table still accepts the pixel, by bisection */
+                float min_thr = threshold + 1;
+                float max_thr = 255.0f;
+                while (min_thr <= max_thr) {
+                    float med_thr = floorf((min_thr + max_thr) * 0.5f);
+                    if (is_corner_quick(lut, px, c, med_thr))
+                        min_thr = med_thr + 1.0f;
+                    else
+                        max_thr = med_thr - 1.0f;
+                }
+                *out = max_thr;
+            } else if (lut[dark] || lut[bright]) { /* :225 */
                 float response_bright = 0.0f, response_dark = 0.0f;
                 for (int i = 0; i < 16; i++) { /* :248-253 */
                     float absdiff = fabsf(px[i] - c) - threshold;
@@ -621,6 +659,7 @@ void oracle_reproject_points(float *pos_out, const double *points_prev, int n, c
             x = dx;
             y = dy;
         }
+        if (intrin->model == 3) orbfe_ftheta_distort(&x, &y, intrin->coeffs[0]); /* RS2_DISTORTION_FTHETA :32-38 */
         pos_out[2 * idx] = x * intrin->fx + intrin->ppx;
         pos_out[2 * idx + 1] = y * intrin->fy + intrin->ppy;
     }
@@ -697,9 +736,9 @@ int oracle_keypoint_pixel_to_point(const uint32_t *aligned_depth, const oracle_i
  * observable here: PARITY UNPINNED at the ulp level, as for a8 / a9); `static_cast<int>(v + 0.5f)`
  * is CUDA's cvt.rzi.s32.f32 -- truncation that SATURATES and maps NaN to 0 (other_point z = 0 gives
  * inf / NaN pixels, which the reference then treats like any other pair of corners).
- * The f-theta branch of project_point_to_pixel (:44-50) calls double atan / tan from libdevice: not
- * restated, a caller with model 3 gets "unsupported" (return -1); deprojecting from model 1 or 3
- * trips the reference's device asserts (:62-63): -1 as well.
+ * The f-theta branch of project_point_to_pixel (:44-50) is orbfe_ftheta_distort (include/orbfe_math.h: float atanf /
+ * tanf, the overloads nvcc picks for float operands; the build's deterministic versions, unpinned at the ulp level);
+ * deprojecting from model 1 or 3 trips the reference's device asserts (:62-63): return -1.
  * kernel_depth_to_other's atomicMin over a rectangle is order-free: the result is the minimum raw
  * depth over all depth pixels whose mapped rectangle [p0, p1] covers the output pixel.
  * ------------------------------------------------------------------------------------ */
@@ -767,6 +806,7 @@ static void oracle_transfer_pixel(int32_t *mapped_xy, const oracle_intrinsics *d
             x = dx;
             y = dy;
         }
+        if (oin->model == 3) orbfe_ftheta_distort(&x, &y, oin->coeffs[0]); /* RS2_DISTORTION_FTHETA :44-50 */
         other_pixel[0] = x * oin->fx + oin->ppx;
         other_pixel[1] = y * oin->fy + oin->ppy;
         mapped_xy[0] = cvt_rzi_s32_f32(other_pixel[0] + 0.5f);
@@ -779,7 +819,7 @@ int oracle_align_depth_to_other(uint32_t *aligned_out, const uint16_t *depth_in,
                                 const oracle_intrinsics *din, const oracle_intrinsics *oin,
                                 const oracle_extrinsics *e)
 {
-    if (din->model == 1 || din->model == 3 || oin->model == 3) return -1;
+    if (din->model == 1 || din->model == 3) return -1;
     const int gx = 32 * ((image_width + 31) / 32), gy = 32 * ((image_height + 31) / 32);
     const int dw = din->width, dh = din->height, ow = oin->width, oh = oin->height;
     const int mx = gx < dw ? gx : dw, my = gy < dh ? gy : dh; /* depth pixels the grid reaches */

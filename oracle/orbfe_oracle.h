@@ -67,6 +67,11 @@ void oracle_fast_calculate_lut(uint8_t *lut, int min_arc);
 void oracle_fast_calc_corner_response(int w, int h, int pitch, const uint8_t *img, int hb,
                                       int vb, const uint8_t *lut, float threshold,
                                       int resp_pitch_elems, float *resp);
+/* ... with the reference's fast_score argument: 0 SUM_OF_ABS_DIFF_ALL (fast.cu:233-241), 1 SUM_OF_ABS_DIFF_ON_ARC
+ * (:243-255), 2 MAX_THRESHOLD (:256-283, bisection with fast_gpu_is_corner_quick :126-148) */
+void oracle_fast_calc_corner_response_score(int w, int h, int pitch, const uint8_t *img, int hb,
+                                            int vb, const uint8_t *lut, float threshold, int score,
+                                            int resp_pitch_elems, float *resp);
 void oracle_grid_nms(const oracle_level *levels, int n_levels, int cell, float *pos /*x,y*/,
                      float *score, int32_t *level);
 void oracle_detect(const oracle_level *levels, int n_levels, int cell, const uint8_t *lut,

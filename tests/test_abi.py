@@ -80,7 +80,7 @@ def test_align_depth_argument_validation_needs_no_device():
     call = lambda scale, d, o: lib.orbfe_align_depth_to_other(fake, fake, None, scale, 64, 48, C.byref(d), C.byref(o), C.byref(ex), None)
     assert lib.orbfe_align_depth_to_other(None, fake, None, 0.001, 64, 48, C.byref(ok), C.byref(ok), C.byref(ex), None) == orbfe.ERR_INVALID_ARG
     assert call(float("inf"), ok, ok) == orbfe.ERR_INVALID_ARG
-    for dm, om in ((1, 0), (3, 0), (0, 3)):
+    for dm, om in ((1, 0), (3, 0), (1, 3)):  # forward-distorted DEPTH models; f-theta on the other camera is supported
         d = orbfe.Intrinsics(64, 48, 32.0, 24.0, 50.0, 50.0, dm, (C.c_float * 5)())
         o = orbfe.Intrinsics(64, 48, 32.0, 24.0, 50.0, 50.0, om, (C.c_float * 5)())
         assert call(0.001, d, o) == orbfe.ERR_UNSUPPORTED

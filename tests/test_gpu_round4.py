@@ -121,7 +121,7 @@ def test_align_depth_rejects_what_the_reference_cannot_run(gpu):
     d, o, e, scale = synth.rig("identity", 32, 32)
     buf = torch.zeros(32 * 32, dtype=torch.int32, device="cuda")
     L = orbfe.lib()
-    for dm, om in [(1, 0), (3, 0), (0, 3)]:
+    for dm, om in [(1, 0), (3, 0), (1, 3)]:  # forward-distorted DEPTH models; f-theta on the other camera runs (round 5)
         dd, oo = list(d), list(o)
         dd[6], oo[6] = dm, om
         rc = L.orbfe_align_depth_to_other(buf.data_ptr(), buf.data_ptr(), None, scale, 32, 32, C.byref(intr(orbfe, dd)),

@@ -5,7 +5,10 @@
     sources with a pitch, and the slot state machine's refusals;
   * 8e, the branches of liborbfe_dist.so under `world > 1` (grouped ncclSend / ncclRecv, root placement, exact-length
     packing, the all-reduce), executed on ONE GPU by 2 and 3 ranks over a test-only loopback transport that stands in for
-    librccl.so.1 (tests/fake_rccl): worker processes without torch, and examples/multi_gpu_port with both threads on device 0.
+    librccl.so.1 (tests/fake_rccl): worker processes without torch, and examples/multi_gpu_port with both threads on device 0;
+  * the stage boundary's holes: SUM_OF_ABS_DIFF_ALL and MAX_THRESHOLD of orbfe_fast_calc_corner_response (fast.cu:233-241,
+    :256-283), the f-theta projection (cuda-align.cu:44-50, post_processing.cu:32-38), camera structs passed as DEVICE
+    pointers as the reference does (buildStream.cpp:391-393).
 The oracle is unpinned by the reference (it holds no tests); see oracle/orbfe_oracle.h."""
 import ctypes as C
 import json
@@ -17,7 +20,8 @@ import numpy as np
 import pytest
 
 from orbfe import synth
-from test_gpu_parity import dev, stream
+from test_align_oracle import extr, intr
+from test_gpu_parity import FRAMES, bits, dev, pitched, stream
 
 pytestmark = pytest.mark.gpu
 
@@ -307,3 +311,158 @@ def test_cpp_multi_gpu_port_two_ranks_on_one_device(gpu, oracle_mod, tmp_path, e
         ref = oracle_mod.extract_frame(frames[f], ocfg)
         assert counts[f] == ref["count"]
         assert rec[f, :counts[f]].tobytes() == ref["records"].tobytes()
+
+
+# ------------------------------------------------------------------ stage boundary: the other fast_score values
+@pytest.mark.parametrize("score", [0, 2])
+@pytest.mark.parametrize("kind,w,h,arc,thr", [("dense", 640, 480, 9, 13.0), ("rects", 848, 480, 12, 13.0),
+                                              ("uniform", 100, 72, 10, 7.5), ("checker", 96, 64, 9, 40.0),
+                                              ("uniform", 67, 35, 12, 0.0)])
+def test_fast_score_modes_stage(gpu, oracle_mod, kind, w, h, arc, thr, score):
+    """orbfe_fast_calc_corner_response with the reference's other two score arguments (enum fast_score, fast.cuh:18-23):
+    0 = SUM_OF_ABS_DIFF_ALL (fast.cu:233-241), 2 = MAX_THRESHOLD (:256-283, bisection).  Bit patterns against the
+    oracle, fractional and zero thresholds included, borders and pitch padding untouched."""
+    torch, orbfe = gpu
+    img = oracle_mod.gaussian_blur_3x3(FRAMES[kind](w, h)) if kind != "checker" else FRAMES[kind](w, h)
+    lut_np = oracle_mod.fast_lut(arc)
+    ref = oracle_mod.fast_response(img, lut_np, thr, score=score)
+    d_img, d_lut = pitched(torch, img, w + 4), dev(torch, lut_np)
+    resp = torch.full((h, w + 8), -3.0, dtype=torch.float32, device="cuda")
+    orbfe.check(orbfe.lib().orbfe_fast_calc_corner_response(w, h, w + 4, d_img.data_ptr(), 3, 3, d_lut.data_ptr(), thr, arc, score,
+                                                            w + 8, resp.data_ptr(), stream(torch)))
+    got = resp.cpu().numpy()
+    np.testing.assert_array_equal(bits(got[:, :w]), bits(ref))
+    assert (got[:, w:] == -3.0).all()
+    if kind in ("dense", "uniform"):
+        assert (ref > 0).sum() > 10
+    if score == 2 and (ref > 0).any():
+        assert ref[ref > 0].min() >= thr  # never below the threshold it was accepted at
+
+
+def test_fast_score_argument_is_validated(gpu):
+    torch, orbfe = gpu
+    one = torch.zeros(65536, dtype=torch.uint8, device="cuda")
+    resp = torch.zeros(64 * 64, dtype=torch.float32, device="cuda")
+    call = lambda score, thr: orbfe.lib().orbfe_fast_calc_corner_response(64, 64, 64, one.data_ptr(), 3, 3, one.data_ptr(), thr, 9,
+                                                                          score, 64, resp.data_ptr(), stream(torch))
+    assert call(3, 13.0) == orbfe.ERR_INVALID_ARG and call(-1, 13.0) == orbfe.ERR_INVALID_ARG
+    assert call(2, float("nan")) == orbfe.ERR_INVALID_ARG and call(2, float("inf")) == orbfe.ERR_INVALID_ARG
+    assert call(2, 13.0) == orbfe.OK and call(0, 13.0) == orbfe.OK
+
+
+# ------------------------------------------------------------------ f-theta (rs2 distortion model 3) on the projecting side
+FTHETA = [0.92, 0.0, 0.0, 0.0, 0.0]  # coeffs[0]: the lens' field-of-view parameter, radians
+
+
+@pytest.mark.parametrize("size", [(848, 480, 848, 480), (101, 67, 80, 60), (424, 240, 848, 480)])
+@pytest.mark.parametrize("kind", ["d435", "distorted"])
+def test_align_depth_ftheta_other_camera(gpu, oracle_mod, size, kind):
+    """orbfe_align_depth_to_other / _batch with other.model = 3 (RS2_DISTORTION_FTHETA, cuda-align.cu:44-50), bit for bit
+    against the oracle ("distorted": the depth side carries the inverse Brown-Conrady polynomial at the same time)."""
+    torch, orbfe = gpu
+    dw, dh, ow, oh = size
+    d, o, e, scale = synth.rig(kind, dw, dh, ow, oh)
+    o = list(o)
+    o[6], o[7] = 3, FTHETA
+    depth = synth.depth_frames(dw, dh, 3, first_index=40 + dw)
+    iw, ih = max(dw, ow), max(dh, oh)
+    want = [oracle_mod.align_depth_to_other(depth[f], scale, iw, ih, intr(oracle_mod, d), intr(oracle_mod, o), extr(oracle_mod, e))[0]
+            for f in range(3)]
+    d_depth = dev(torch, depth.view(np.int16))
+    d_out = torch.full((3, oh, ow), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+    orbfe.check(orbfe.lib().orbfe_align_depth_to_other(d_out[0].data_ptr(), d_depth[0].data_ptr(), None, scale, iw, ih,
+                                                       C.byref(intr(orbfe, d)), C.byref(intr(orbfe, o)), C.byref(extr(orbfe, e)),
+                                                       stream(torch)))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(d_out[0].cpu().numpy().view(np.uint32), want[0])
+    assert (want[0] != 0).mean() > 0.2
+    d_out.fill_(0x5A5A5A5A)
+    orbfe.check(orbfe.lib().orbfe_align_depth_batch(d_out.data_ptr(), ow * oh, d_depth.data_ptr(), dw * dh, 3, scale,
+                                                    C.byref(intr(orbfe, d)), C.byref(intr(orbfe, o)), C.byref(extr(orbfe, e)),
+                                                    stream(torch)))
+    torch.cuda.synchronize()
+    for f in range(3):
+        np.testing.assert_array_equal(d_out[f].cpu().numpy().view(np.uint32), want[f])
+
+
+def test_reproject_points_ftheta(gpu, oracle_mod):
+    """orbfe_reproject_points with model 3 (post_processing.cu:32-38), the origin (r = 0: 0 / 0 as in the reference) included."""
+    torch, orbfe = gpu
+    rng = np.random.default_rng(33)
+    n = 1000
+    pts = np.stack([rng.normal(size=n) * 400, rng.normal(size=n) * 300, rng.uniform(300, 5000, n)], 1)
+    pts[0] = (0.0, 0.0, 1000.0)
+    T = np.eye(4)
+    T[:3, 3] = (5.0, -2.0, 11.0)
+    T[0, 3] = 0.0
+    T[1, 3] = 0.0
+    k = (848, 480, 421.5, 237.25, 615.5, 615.25, 3, FTHETA)
+    d_pts = dev(torch, pts)
+    out = torch.full((n, 2), -1.0, dtype=torch.float32, device="cuda")
+    Tc = (C.c_double * 16)(*np.ascontiguousarray(T.T).reshape(-1))
+    orbfe.check(orbfe.lib().orbfe_reproject_points(out.data_ptr(), d_pts.data_ptr(), n, Tc, C.byref(intr(orbfe, k)), stream(torch)))
+    ref = oracle_mod.reproject_points(pts, T, intr(oracle_mod, k))
+    np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    assert np.isnan(ref[0]).all() and np.isfinite(ref[1:]).all() and ref[1:, 0].std() > 10
+    # against libm in float64: a few ulp of float
+    x, y = pts[1:, 0] / (pts[1:, 2] + 11.0), pts[1:, 1] / (pts[1:, 2] + 11.0)
+    r = np.sqrt(x * x + y * y)
+    rd = np.arctan(2 * r * np.tan(FTHETA[0] / 2)) / FTHETA[0]
+    np.testing.assert_allclose(ref[1:, 0], x * rd / r * k[4] + k[2], rtol=0, atol=2e-3)
+    np.testing.assert_allclose(ref[1:, 1], y * rd / r * k[5] + k[3], rtol=0, atol=2e-3)
+
+
+# ------------------------------------------------------------------ camera structs handed over as DEVICE pointers
+def _on_device(torch, struct):
+    return torch.from_numpy(np.frombuffer(bytes(struct), dtype=np.uint8).copy()).cuda()
+
+
+def test_camera_structs_as_device_pointers(gpu, oracle_mod):
+    """The reference passes DEVICE copies of rs2_intrinsics / rs2_extrinsics (_d_depth_intrinsics, _d_rgb_intrinsics,
+    _d_depth_rgb_extrinsics: SlamGpuPipeline.cpp:53-55, buildStream.cpp:391-393, :469, post_processing.cuh:45).  The three
+    entry points that take them accept either kind of pointer: same results as with host structs, i.e. the oracle's."""
+    torch, orbfe = gpu
+    L = orbfe.lib()
+    dw, dh = 424, 240
+    d, o, e, scale = synth.rig("d435", dw, dh)
+    depth = synth.depth_frame(dw, dh, 77)
+    want, _ = oracle_mod.align_depth_to_other(depth, scale, dw, dh, intr(oracle_mod, d), intr(oracle_mod, o), extr(oracle_mod, e))
+    d_di, d_oi, d_ex = _on_device(torch, intr(orbfe, d)), _on_device(torch, intr(orbfe, o)), _on_device(torch, extr(orbfe, e))
+    d_depth = dev(torch, depth.view(np.int16))
+    d_al = torch.zeros((dh, dw), dtype=torch.int32, device="cuda")
+    as_i = lambda t: C.cast(C.c_void_p(t.data_ptr()), C.POINTER(orbfe.Intrinsics))
+    as_e = lambda t: C.cast(C.c_void_p(t.data_ptr()), C.POINTER(orbfe.Extrinsics))
+    orbfe.check(L.orbfe_align_depth_to_other(d_al.data_ptr(), d_depth.data_ptr(), None, scale, dw, dh, as_i(d_di), as_i(d_oi),
+                                             as_e(d_ex), stream(torch)))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(d_al.cpu().numpy().view(np.uint32), want)
+    d_al2 = torch.zeros((2, dh, dw), dtype=torch.int32, device="cuda")
+    d_depth2 = torch.stack([d_depth, d_depth])
+    orbfe.check(L.orbfe_align_depth_batch(d_al2.data_ptr(), dw * dh, d_depth2.data_ptr(), dw * dh, 2, scale, as_i(d_di), as_i(d_oi),
+                                          as_e(d_ex), stream(torch)))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(d_al2[1].cpu().numpy().view(np.uint32), want)
+    # keypoint_pixel_to_point with the device intrinsics on that aligned depth
+    rng = np.random.default_rng(8)
+    n = 300
+    pos = np.stack([rng.integers(0, dw, n), rng.integers(0, dh, n)], 1).astype(np.float32)
+    score = rng.choice([0.0, 2.0, 57.0], n).astype(np.float32)
+    desc = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+    _, ref_pts, _, ref_n = oracle_mod.keypoint_pixel_to_point(want, intr(oracle_mod, o), pos, score, desc, fix_depth_index=1)
+    d_pos, d_score, d_desc = dev(torch, pos), dev(torch, score), dev(torch, desc.view(np.int32))
+    o_pos = torch.zeros((n, 2), dtype=torch.float32, device="cuda")
+    o_pts = torch.zeros((n, 3), dtype=torch.float64, device="cuda")
+    o_desc = torch.zeros(n, dtype=torch.int32, device="cuda")
+    o_n = torch.zeros(1, dtype=torch.int32, device="cuda")
+    orbfe.check(L.orbfe_keypoint_pixel_to_point(d_al.data_ptr(), as_i(d_oi), dw, dh, o_pos.data_ptr(), d_pos.data_ptr(),
+                                                d_score.data_ptr(), o_pts.data_ptr(), o_desc.data_ptr(), d_desc.data_ptr(), n,
+                                                o_n.data_ptr(), 1, stream(torch)))
+    m = int(o_n.cpu()[0])
+    assert m == ref_n > 20
+    np.testing.assert_array_equal(o_pts.cpu().numpy()[:m].view(np.uint64), ref_pts.view(np.uint64))
+    # reproject_points with the device intrinsics
+    out = torch.zeros((m, 2), dtype=torch.float32, device="cuda")
+    T = np.eye(4)
+    Tc = (C.c_double * 16)(*T.T.reshape(-1))
+    orbfe.check(L.orbfe_reproject_points(out.data_ptr(), o_pts.data_ptr(), m, Tc, as_i(d_oi), stream(torch)))
+    np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32), oracle_mod.reproject_points(ref_pts, T, intr(oracle_mod, o)).view(np.uint32))

@@ -381,6 +381,47 @@ def test_fast_response_against_a_definition_level_numpy_restatement(oracle_mod, 
         assert (want > 0).any() or kind == "checker"
 
 
+@pytest.mark.parametrize("arc", [9, 12])
+def test_fast_score_modes_against_their_definitions(oracle_mod, arc):
+    """The other two values of the reference's enum fast_score (fast.cuh:18-23) as definitions, nothing shared with the
+    restatement: SUM_OF_ABS_DIFF_ALL = sum of |p - c| over the 16 ring pixels of an accepted pixel (fast.cu:233-241);
+    MAX_THRESHOLD = the largest integer threshold in (t, 255] at which the pixel is still a corner, t itself when there
+    is none (:256-283 finds it by bisection; being a corner is monotone in the threshold, so a linear scan is the same)."""
+    offs = [(0, 3), (-1, 3), (-2, 2), (-3, 1), (-3, 0), (-3, -1), (-2, -2), (-1, -3), (0, -3),
+            (1, -3), (2, -2), (3, -1), (3, 0), (3, 1), (2, 2), (1, 3)]
+    t = 13
+    lut = oracle_mod.fast_lut(arc)
+    for kind, w, h, seed in (("rects", 120, 90, 4), ("uniform", 64, 48, 5)):
+        img = synth.frame(w, h, seed, kind)
+        I = img.astype(np.int32)
+        c = I[3:h - 3, 3:w - 3]
+        ring = np.stack([I[3 + dy:h - 3 + dy, 3 + dx:w - 3 + dx] for dx, dy in offs])
+
+        def corner_at(thr):
+            def has_run(lab):
+                run = np.ones_like(lab)
+                for k in range(arc):
+                    run &= np.roll(lab, -k, axis=0)
+                return run.any(axis=0)
+            return has_run(ring > c + thr) | has_run(ring < c - thr)
+
+        is_corner = corner_at(t)
+        assert is_corner.sum() > 20
+        want = np.zeros((h, w), np.float32)
+        want[3:h - 3, 3:w - 3] = np.where(is_corner, np.abs(ring - c).sum(axis=0), 0)
+        np.testing.assert_array_equal(oracle_mod.fast_response(img, lut, float(t), score=0), want)
+        best = np.full(c.shape, t, np.int32)
+        for thr in range(t + 1, 256):
+            best = np.where(corner_at(thr), thr, best)
+        want = np.zeros((h, w), np.float32)
+        want[3:h - 3, 3:w - 3] = np.where(is_corner, best, 0)
+        got = oracle_mod.fast_response(img, lut, float(t), score=2)
+        np.testing.assert_array_equal(got, want)
+        assert got.max() > t + 20
+        # the live score is untouched by the new argument
+        np.testing.assert_array_equal(oracle_mod.fast_response(img, lut, float(t), score=1), oracle_mod.fast_response(img, lut, float(t)))
+
+
 @pytest.mark.parametrize("radians", [0, 1])
 def test_orientation_and_rbrief_against_definition_level_numpy(oracle_mod, radians):
     """C.6 / C.7 of SURVEY.md Appendix C written down directly in numpy (nothing shared with oracle/orbfe_oracle.c but
