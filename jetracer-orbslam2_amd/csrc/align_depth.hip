@@ -41,11 +41,8 @@ namespace orbfe {
 constexpr int kAlignTileW = 64, kAlignTileH = 16; // depth pixels per workgroup: 256 threads x 4 pixels of one row
 constexpr int kAlignWin = 6144;                    // LDS window, u32 entries (24 KB: six workgroups per CU)
 constexpr uint32_t kAlignMax = 9999999u;           // the reference's sentinel (:265, :277)
-// Profiling aid (tools/build_variant.sh): -DORBFE_ALIGN_ABLATE=1 drops the window flush (no global atomics), 2 also the
-// LDS splat, 3 also the projection arithmetic.  Results are then WRONG; the builds exist to attribute time to phases.
-#ifndef ORBFE_ALIGN_ABLATE
-#define ORBFE_ALIGN_ABLATE 0
-#endif
+// (The phase-ablation builds of the splat kernel -- wrong results by design -- live in tools/experiments/
+// profiling_probes.patch, applied to a scratch copy of the sources by tools/build_variant.sh -p.)
 
 struct AlignArgs {
     orbfe_intrinsics d, o;
@@ -323,9 +320,6 @@ align_splat_kernel(uint32_t *__restrict__ out, const uint16_t *__restrict__ dept
         rw[k] = -1;
         rh[k] = -1;
         int ax, ay, bx, by;
-#if ORBFE_ALIGN_ABLATE >= 3
-        ax = gx + k, ay = gy, bx = gx + k + 1, by = gy + 1;
-#else
         float ua, va, ub, vb;
         if (fast_div) {
             div2_in_range(qa[k][0], qa[k][1], qa[k][2], &ua, &va);
@@ -338,7 +332,6 @@ align_splat_kernel(uint32_t *__restrict__ out, const uint16_t *__restrict__ dept
         }
         to_other_pixel<DO>(A, ua, va, &ax, &ay);
         to_other_pixel<DO>(A, ub, vb, &bx, &by);
-#endif
         // :140: no depth, nothing mapped; :241: skip unless the rectangle's corners are inside; an inverted rectangle
         // writes nothing
         if (raw[k] != 0 && (float)(int)raw[k] * A.scale != 0 && !(ax < 0 || ay < 0 || bx >= A.o.width || by >= A.o.height) &&
@@ -370,9 +363,6 @@ align_splat_kernel(uint32_t *__restrict__ out, const uint16_t *__restrict__ dept
         const int nquads = nq * bh;
         for (int i = tid; i < nquads; i += 256) reinterpret_cast<uint4 *>(s_win)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
         __syncthreads();
-#if ORBFE_ALIGN_ABLATE >= 2
-        if (rw[0] == 0x12345) s_win[tid] = raw[1];
-#else
         // byte addresses inside s_win; entry (dx, dy) of the 3 x 3 block at p0 lands at row_dy + 4 dx.  What the rectangle
         // does not cover goes to the thread's dump word instead -- the select is on the ROW address and the + 4 dx rides in
         // the instruction's offset field (the dump address is pre-biased by - 4 dx; two words of padding keep it inside
@@ -412,12 +402,7 @@ align_splat_kernel(uint32_t *__restrict__ out, const uint16_t *__restrict__ dept
                     for (int dx = dy > 2 ? 0 : 3; dx <= rw[k]; dx++)
                         atomicMin(&s_win[(pk_y(p0[k]) - wy0 + dy) * bwp + (pk_x(p0[k]) - wx0) + dx], raw[k]);
         }
-#endif
         __syncthreads();
-#if ORBFE_ALIGN_ABLATE >= 1
-        if (bwp == 0x12345) out[tid] = s_win[tid] + (uint32_t)(p0[1] + rw[2] + rh[3]);
-        return;
-#endif
         // a wave per window row, CONSECUTIVE lanes on consecutive entries: the touched entries of a row leave as one or
         // two fully used cache lines per atomic instruction (a lane per quad -- four strided atomics -- visits every line
         // four times: measured 2x slower, the L2's atomic rate is per line visit)

@@ -271,16 +271,9 @@ pyramid_fused_kernel(DeviceGeom g, uint8_t *__restrict__ pyr, const uint8_t *__r
 //   D  strict 3x3 maximum test on the positives only; winners atomicMax their nms_key()
 //      into the cell (LDS for cells >= 4 px, global for smaller cells)
 // ------------------------------------------------------------------------------------
-// Profiling aid (tools/phase_counters.sh): -DORBFE_DETECT_STOP_AFTER=n ends detect_tile_kernel after phase n
-// (1 = A tile load, 2 = B compass + compaction, 3 = C ring test), -DORBFE_DESCRIBE_STOP_AFTER=n the tile describe
-// kernel (1 = staging + keypoint list, 2 = moments, 3 = angles).  Results are then WRONG; the builds exist so
-// that PMC passes can attribute instructions and stalls to phases.  0 = the product.
-#ifndef ORBFE_DETECT_STOP_AFTER
-#define ORBFE_DETECT_STOP_AFTER 0
-#endif
-#ifndef ORBFE_DESCRIBE_STOP_AFTER
-#define ORBFE_DESCRIBE_STOP_AFTER 0
-#endif
+// (The stop-after-a-phase and ring-read profiling builds of detect_tile_kernel / describe_tile_kernel -- wrong results by
+// design -- are not in this file: tools/experiments/profiling_probes.patch adds them to a scratch copy of the sources,
+// tools/build_variant.sh -p applies it, tools/phase_counters.sh uses those builds.)
 
 // entry i of the context's tile list (8 bytes, 8-byte aligned) through the constant address space: s_load_dwordx2
 static_assert(sizeof(TileDesc) == 8, "TileDesc is read as one 64-bit scalar load");
@@ -378,44 +371,11 @@ __device__ inline int fast_score_packed(const uint8_t *p, uint32_t t2, int arc, 
     const us2 one = U2(0x00010001u);
     us2 sb = U2(0), sd = U2(0);
     uint32_t bright = 0, dark = 0;
-#ifdef ORBFE_DETECT_RING_ROWS3
-    // Experiment (round 4): the three ring pixels of rows y - 3 and y + 3 (x - 1, x, x + 1) as TWO aligned dwords per row
-    // realigned by v_alignbyte instead of three byte reads, their pairs (ring i, ring i + 8) formed by v_perm with constant
-    // selectors: 6 ds_read_u8 + 3 v_lshl_or -> 2 ds_read2_b32 + 2 v_alignbyte + 3 v_perm per candidate
-    uint32_t prow[3];
-    {
-        const uint8_t *qm = p - 3 * kPxW - 1, *qp = p + 3 * kPxW - 1;
-        const uint32_t shm = (uint32_t)(uintptr_t)qm & 3u, shp = (uint32_t)(uintptr_t)qp & 3u;
-        const uint32_t *am = reinterpret_cast<const uint32_t *>(qm - shm), *ap = reinterpret_cast<const uint32_t *>(qp - shp);
-        const uint32_t Tm = __builtin_amdgcn_alignbyte(am[1], am[0], shm); // [ring 7, 8, 9, -]
-        const uint32_t Tp = __builtin_amdgcn_alignbyte(ap[1], ap[0], shp); // [ring 1, 0, 15, -]
-        prow[0] = __builtin_amdgcn_perm(Tm, Tp, 0x0c050c01u); // ring 0 | ring 8 << 16
-        prow[1] = __builtin_amdgcn_perm(Tm, Tp, 0x0c060c00u); // ring 1 | ring 9 << 16
-        prow[2] = __builtin_amdgcn_perm(Tm, Tp, 0x0c020c04u); // ring 7 | ring 15 << 16
-    }
-#endif
 #pragma unroll
     for (int i = 0; i < 8; i++) { // pair (ring i, ring i + 8)
-#ifdef ORBFE_DETECT_RING_NOLDS
-        // Profiling aid (results are WRONG): the 16 ring bytes come from registers instead of LDS, the vector instruction
-        // stream is otherwise the same -- the time this build saves is the MOST any rewrite of the ring reads (aligned
-        // dwords, ds_read2, bytes in place ...) could save
-        const uint32_t v0 = (c + (uint32_t)(37 * i + 11)) & 255u, v1 = (c ^ (uint32_t)(29 * i + 5)) & 255u;
-        const us2 v = U2(v0 | (v1 << 16));
-#elif defined(ORBFE_DETECT_RING_ROWS3)
-        us2 v;
-        if (i == 0 || i == 1 || i == 7) {
-            v = U2(prow[i == 7 ? 2 : i]);
-        } else {
-            const uint32_t v0 = p[ring_dy(i) * kPxW + ring_dx(i)];
-            const uint32_t v1 = p[ring_dy(i + 8) * kPxW + ring_dx(i + 8)];
-            v = U2(v0 | (v1 << 16));
-        }
-#else
         const uint32_t v0 = p[ring_dy(i) * kPxW + ring_dx(i)];
         const uint32_t v1 = p[ring_dy(i + 8) * kPxW + ring_dx(i + 8)];
         const us2 v = U2(v0 | (v1 << 16));
-#endif
         const us2 ab = ssub(v, hi), ad = ssub(lo, v); // score terms v - (c+t), (c-t) - v, or 0
         sb = U2(U1(sb) + U1(ab)); // 8 terms <= 255 per 16-bit lane: no carry between the lanes, so a full-rate v_add_u32
         sd = U2(U1(sd) + U1(ad));
@@ -576,7 +536,6 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
         for (int i = tid; i < ncx * ncy; i += 256) s_key[i] = 0u;
     if (tid == 0) s_qcount = 0;
     __syncthreads();
-    if (ORBFE_DETECT_STOP_AFTER == 1) return;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint16_t *q1 = s_q + 256; // the queue proper
     // slot of this wave's p-th positive: in place, inside the batches the wave itself has consumed (64 (wv + 4 j) ..)
@@ -695,10 +654,6 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
     }
     __syncthreads(); // the queue is complete
     const int nq = s_qcount;
-    if (ORBFE_DETECT_STOP_AFTER == 2) {
-        if (nq == 12345) cellkey[0] = q1[lane]; // keeps the queue alive
-        return;
-    }
 
     // ---- C: full ring test, batches of 64 candidates dealt round-robin to the waves
     int n2 = 0;
@@ -720,10 +675,6 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
         n2 += (int)__popcll(m);
     }
     __syncthreads(); // every wave's scores are in s_sc
-    if (ORBFE_DETECT_STOP_AFTER == 3) {
-        if (n2 == 12345) cellkey[0] = s_sc[tid] + q1[lane];
-        return;
-    }
 
     if (STAGE && st.resp[l]) { // the tile's part of the caller's response map, zeros included
         float *rp = st.resp[l];
@@ -1443,9 +1394,6 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
     //      legal, and what lies outside the image is zeroed afterwards (border tiles only).
 #pragma unroll
     for (int t = 0; t < (G::kChunks + kDescThreads - 1) / kDescThreads; t++) {
-#ifdef ORBFE_DESCRIBE_NOSTAGE // (timing experiment: no tile staging at all; results are wrong)
-        break;
-#endif
         const int q = kDescThreads * t + tid;
         if (kDescThreads * (t + 1) <= G::kChunks || q < G::kChunks) {
             const int r = q / G::kChunksRow, cc = q - r * G::kChunksRow;
@@ -1520,13 +1468,8 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
         // uniform: no (further) keypoint in this tile.  WRITE-BACK INVARIANT of the scalar descriptor stores below: this
         // is the only exit a wave can take AFTER it has issued s_store_dwordx4 (passes 2.. of the DL form), and it is safe
         // because every pass ends with s_waitcnt lgkmcnt(0) + s_dcache_wb before it loops back here -- a wave never
-        // reaches this return with an unwritten scalar store.  (The STOP_AFTER returns are profiling builds that store
-        // nothing.)  tests/test_gpu_round4.py::test_scalar_descriptor_stores_equal_the_vector_store_build A/Bs the path.
+        // reaches this return with an unwritten scalar store.  tests/test_gpu_round4.py::test_scalar_descriptor_stores_equal_the_vector_store_build A/Bs the path.
         if (nkp == 0) return;
-        if (ORBFE_DESCRIBE_STOP_AFTER == 1) {
-            if (nkp == 12345) records[0].x = (float)s_tile[tid];
-            return;
-        }
         if (first) {
             // ---- border tiles: zero what the moments exclude / what lies outside the image: rows gy <= 0 and
             //      gy >= H, columns gx <= 0 and gx >= W (only the strips concerned are touched)
@@ -1609,10 +1552,6 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
             }
         }
         __syncthreads();
-        if (ORBFE_DESCRIBE_STOP_AFTER == 2) {
-            if (nkp == 12345) records[0].x = (float)s_mom[tid & 127];
-            return;
-        }
         // ---- phase B: one lane per keypoint: atan2f and the steering cos / sin, ONCE per pass
         if (wv == 0 && lane < nkp) {
             const float ang = orbfe_atan2f((float)s_mom[2 * lane + 1], (float)s_mom[2 * lane]);
@@ -1635,10 +1574,6 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
             *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(records + (size_t)f * g.cap) + s_kslot[lane] + 16) = __float_as_uint(ang);
         }
         __syncthreads();
-        if (ORBFE_DESCRIBE_STOP_AFTER == 3) {
-            if (nkp == 12345) records[0].x = s_ang[tid & 63] + s_cos[tid & 63] + s_sin[tid & 63];
-            return;
-        }
         // ---- phase C: descriptors, keypoints dealt round-robin to the waves.  A keypoint's 256 bits are four
         //      wave-uniform ballots, i.e. SGPR pairs: they go to the record by SCALAR stores (s_store_dwordx4: gfx950
         //      still has them; tools/sstore_probe.hip checks them against vector stores into the same cache lines),
@@ -1724,7 +1659,7 @@ describe_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const uint32
                 }
             }
         }
-#if !defined(ORBFE_DESC_VECTOR_STORE) && !defined(ORBFE_DESC_NO_WB)
+#if !defined(ORBFE_DESC_VECTOR_STORE)
         // scalar stores sit in the scalar data cache until written back; the write-back covers only stores that
         // have reached the cache, hence the wait
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb" ::: "memory");

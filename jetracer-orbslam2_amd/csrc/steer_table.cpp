@@ -15,18 +15,11 @@ namespace orbfe {
 // Round schedule (tools/describe_schedule.py): in round r lane t gathers the samples of test 64 * p_t[r] + t, p_t a
 // two-stage butterfly of four bits per lane (bit 0 swaps rounds 0,1; bit 1 rounds 2,3; then bit 2 rounds 0,2; bit 3
 // rounds 1,3), chosen so that the 64 byte gathers of a round spread over the LDS banks.  Speed only: the kernel puts
-// the ballots back in order with the four masks (any table gives the same descriptors; ORBFE_SCHED_SCRAMBLE builds
-// another one for the parity tests).
-#if defined(ORBFE_SCHED_SCRAMBLE)
-static const uint8_t kSchedBits[64] = {5, 12, 3, 9, 15, 0, 6, 10, 1, 7, 14, 2, 8, 13, 4, 11, 11, 4, 13, 8, 2, 14, 7, 1, 10, 6, 0, 15, 9, 3, 12, 5,
-                                       6, 1, 9, 14, 3, 12, 5, 10, 15, 0, 7, 8, 13, 2, 11, 4, 4, 11, 2, 13, 8, 7, 0, 15, 10, 5, 12, 3, 14, 9, 1, 6};
-#elif defined(ORBFE_SCHED_PLAIN)
-static const uint8_t kSchedBits[64] = {0};
-#else
+// the ballots back in order with the four masks (any table gives the same descriptors; tools/experiments/
+// profiling_probes.patch holds two other schedules the parity tests were run on).
 // LDS cycles per keypoint for the 8 gathers: 52.3 plain -> 35.0 scheduled (ideal 16); tools/describe_schedule.py 40000 3
 static const uint8_t kSchedBits[64] = {3, 14, 0, 12, 4, 8, 4, 3, 8, 15, 0, 2, 1, 12, 2, 15, 0, 8, 8, 8, 1, 7, 0, 1, 9, 12, 5, 5, 0, 4, 4, 2,
                                        1, 7, 10, 0, 0, 1, 5, 4, 2, 4, 4, 9, 0, 4, 1, 12, 4, 14, 1, 5, 0, 9, 12, 9, 2, 4, 0, 8, 4, 12, 0, 4};
-#endif
 
 static void sched_perm(int bt, int p[4])
 {

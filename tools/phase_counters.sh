@@ -1,9 +1,10 @@
 #!/bin/bash
 # Per-phase instruction / stall counters of the detect and describe kernels: PMC passes over
-# ablated builds (tools/build_variant.sh det1..det3, desc1..desc3 = -DORBFE_*_STOP_AFTER=n) and the product.
+# ablated builds (det1..det3, desc1..desc3 = -DORBFE_*_STOP_AFTER=n on tools/experiments/profiling_probes.patch) and the product.
 # usage (through gpurun, from the repo root):  tools/phase_counters.sh <tag> [variants...]
 # -> gpurun_out/<tag>/<variant>.json + a table on stdout.  Build the variants BEFORE the gpurun call (hipcc
-# cross-compiles here):  for n in 1 2 3; do tools/build_variant.sh det$n -DORBFE_DETECT_STOP_AFTER=$n; done
+# cross-compiles here):  tools/build_probe_variants.sh   (applies the patch to a scratch copy of the sources; the product
+# sources carry none of these macros)
 TAG=${1:-phases}; shift
 VARS=${@:-base det1 det2 det3 desc1 desc2 desc3}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT

@@ -1,6 +1,6 @@
 #!/bin/bash
 # align_depth: phase ablations (variants al1..al3 = no flush / no LDS splat / no projection; build them first on the build host:
-#   for n in 1 2 3; do tools/build_variant.sh al$n -DORBFE_ALIGN_ABLATE=$n; done) and PMC passes
+#   tools/build_probe_variants.sh align: al1..al3 = -DORBFE_ALIGN_ABLATE=n on tools/experiments/profiling_probes.patch) and PMC passes
 TAG=${1:-r4b}; OUT=gpurun_out/$TAG; mkdir -p $OUT; R=$(pwd)
 B="python3 $R/bench.py --mode align --steps 10 --warmup 3 --no-cpu-baseline"
 for v in base al1 al2 al3; do
