@@ -2580,6 +2580,7 @@ int orbfe_create(const orbfe_config *cfg, orbfe_ctx **out)
     if (g.cap <= kMmaMaxKeypoints) { // scratch of the matrix-core matcher
         if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_mexp, B * ctx->cap_pad * 128);
         if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_mkey, B * ctx->cap_pad * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_mkey4, B * ctx->cap_pad * sizeof(float4));
     }
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_tiles, (tiles.size() + 1) * sizeof(TileDesc));
     if (e == hipSuccess && !tiles.empty())
@@ -2613,6 +2614,7 @@ void orbfe_destroy(orbfe_ctx *ctx)
     if (ctx->d_bd32) (void)hipFree(ctx->d_bd32);
     if (ctx->d_mexp) (void)hipFree(ctx->d_mexp);
     if (ctx->d_mkey) (void)hipFree(ctx->d_mkey);
+    if (ctx->d_mkey4) (void)hipFree(ctx->d_mkey4);
     if (ctx->d_momw) (void)hipFree(ctx->d_momw);
     delete ctx;
 }
@@ -2880,7 +2882,7 @@ int orbfe_match_pairs(orbfe_ctx *ctx, const orbfe_keypoint *d_records, const int
         break;
     case kMatchMfma:
         launch_match_mfma(d_records, d_counts, n_frames, n_pairs, first, stride, cap, ctx->cap_pad, max_distance, ctx->d_mexp,
-                          ctx->d_mkey, d_idx, d_dist, S(stream));
+                          ctx->d_mkey, ctx->d_mkey4, d_idx, d_dist, S(stream));
         break;
     case kMatchWindow256:
         launch_match_bucket(d_records, d_counts, n_pairs, cap, first, stride, g, inv_cell, ctx->d_bend, ctx->d_bsorted,
