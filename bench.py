@@ -292,7 +292,7 @@ def match_microbench(args, torch, np, orbfe, dev, json_out):
                  "matched": int((d_idx[:n] >= 0).sum().item())}
             if disp["match_examines"] == "all_pairs":
                 r["gpairs_per_s"] = pairs / (ms * 1e-3) / 1e9
-                if "mfma" in disp["match"]:
+                if "mfma" in disp["match"] or "match_tile_kernel" in disp["match"]:
                     r["mfma"] = {"bound": "mfma", "unit": "TFLOP/s", "peak": FP4_MFMA_PEAK_TFLOPS,
                                  "achieved": 512.0 * pairs / (ms * 1e-3) / 1e12,
                                  "frac": 512.0 * pairs / (ms * 1e-3) / 1e12 / FP4_MFMA_PEAK_TFLOPS}
@@ -928,7 +928,7 @@ def main():
         disp = ctx.dispatch_info(max(B, 1), mm["mode"] if mm else 1, mm["window"] if mm else -1)
         if not mm:
             disp["match"], disp["match_examines"] = None, None
-        mfma_match = bool(mm) and "match_mfma_kernel" in (disp["match"] or "")
+        mfma_match = bool(mm) and ("match_mfma_kernel" in (disp["match"] or "") or "match_tile_kernel" in (disp["match"] or ""))
         kernels = {k: disp[k] for k in names}
         # PMC-derived numbers (profiles/traffic.json: rocprofv3 --pmc passes, tools/collect_profiles.sh) are used only
         # when they were measured on THIS source (orbfe.source_hash()); they are per launch of `batch` frames and scale

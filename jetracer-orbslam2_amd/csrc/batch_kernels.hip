@@ -2580,7 +2580,9 @@ int orbfe_create(const orbfe_config *cfg, orbfe_ctx **out)
     if (g.cap <= kMmaMaxKeypoints) { // scratch of the matrix-core matcher
         if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_mexp, B * ctx->cap_pad * 128);
         if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_mkey, B * ctx->cap_pad * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_mkey4, B * ctx->cap_pad * sizeof(float4));
+        const char *mf = getenv("ORBFE_MATCH"); // A/B timing of the matrix-core matcher's forms on one box; the tests run both
+        if (mf && !strcmp(mf, "stream")) ctx->match_form = 1;
+        else if (mf && !strcmp(mf, "tile")) ctx->match_form = 2;
     }
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_tiles, (tiles.size() + 1) * sizeof(TileDesc));
     if (e == hipSuccess && !tiles.empty())
@@ -2614,7 +2616,6 @@ void orbfe_destroy(orbfe_ctx *ctx)
     if (ctx->d_bd32) (void)hipFree(ctx->d_bd32);
     if (ctx->d_mexp) (void)hipFree(ctx->d_mexp);
     if (ctx->d_mkey) (void)hipFree(ctx->d_mkey);
-    if (ctx->d_mkey4) (void)hipFree(ctx->d_mkey4);
     if (ctx->d_momw) (void)hipFree(ctx->d_momw);
     delete ctx;
 }
@@ -2882,7 +2883,7 @@ int orbfe_match_pairs(orbfe_ctx *ctx, const orbfe_keypoint *d_records, const int
         break;
     case kMatchMfma:
         launch_match_mfma(d_records, d_counts, n_frames, n_pairs, first, stride, cap, ctx->cap_pad, max_distance, ctx->d_mexp,
-                          ctx->d_mkey, ctx->d_mkey4, d_idx, d_dist, S(stream));
+                          ctx->d_mkey, ctx->match_form, d_idx, d_dist, S(stream));
         break;
     case kMatchWindow256:
         launch_match_bucket(d_records, d_counts, n_pairs, cap, first, stride, g, inv_cell, ctx->d_bend, ctx->d_bsorted,
@@ -2917,7 +2918,11 @@ int orbfe_dispatch_info(const orbfe_ctx *ctx, int n_frames, int mode, int window
     switch (match_path(ctx, n_frames, mode, window)) {
     case kMatchRefWindow: match = "match_bucket_kernel+match_window_ref_kernel"; break;
     case kMatchRefLiteral: match = "match_batch_ref_kernel"; break;
-    case kMatchMfma: match = "match_expand_kernel+match_mfma_kernel"; break;
+    case kMatchMfma: {
+        const int np = (n_frames - 2) / 1 + 1; // orbfe_match_batch's pairs (orbfe_match_pairs with another stride has fewer)
+        match = match_mfma_uses_tile(np > 0 ? np : 0, ctx->cap_pad, ctx->match_form) ? "match_tile_kernel" : "match_expand_kernel+match_mfma_kernel";
+        break;
+    }
     case kMatchWindow256: match = "match_bucket_kernel+match_window_kernel"; break;
     case kMatchValu256: match = "match_gather_kernel+match_batch_256_kernel"; break;
     }

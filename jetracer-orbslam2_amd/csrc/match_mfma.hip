@@ -35,8 +35,9 @@ namespace orbfe {
 //     2S; with both scales 0 hipcc emits the plain v_mfma_f32_16x16x128_f8f6f4 (a 64-bit
 //     encoding, no scale operands to read) and the same loop runs 5 % faster.
 // Measured (tools/mfma_probe.hip, MI355X): the MFMA alone issues at 19 T pairs/s; with the
-// epilogue as v_max_f32 the step structure tops out at 12.5 T (VALU issue does not overlap these
-// MFMAs), with v_max3_f32 at 14.7 T; the kernel reaches ~12 T.
+// epilogue as v_max_f32 the step structure tops out at 12.5 T, with v_max3_f32 at 14.7 T; this
+// kernel reaches ~12 T.  It serves small and medium calls; large calls take (3) match_tile_kernel
+// below, which needs neither (1) nor its scratch.
 constexpr int kMmaS = 16384;
 constexpr float kKeyUnit = 1.0f / (2 * kMmaS); // keys are carried as (integer key) / 2S: a power of two, exact
 constexpr int kRing = 4;                 // candidate blocks in flight per wave
@@ -64,7 +65,7 @@ __device__ __forceinline__ uint32_t spread_bits_e2m1(uint32_t x)
 
 __global__ void __launch_bounds__(256)
 match_expand_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *__restrict__ counts, int cap, int capP,
-                    uint4 *__restrict__ mexp, float *__restrict__ mkey, float4 *__restrict__ mkey4)
+                    uint4 *__restrict__ mexp, float *__restrict__ mkey)
 {
     const int f = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
     const int i = t >> 3, w = t & 7; // 8 consecutive lanes = the 8 words of keypoint i
@@ -79,13 +80,7 @@ match_expand_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *_
     const uint4 e = make_uint4(spread_bits_e2m1(word), spread_bits_e2m1(word >> 8), spread_bits_e2m1(word >> 16),
                                spread_bits_e2m1(word >> 24));
     mexp[(size_t)f * capP * 8 + (size_t)(i >> 4) * 128 + (w >> 2) * 64 + (w & 3) * 16 + (i & 15)] = e;
-    if (w == 0) {
-        const float k = live ? -(float)(pop * kMmaS + i) * kKeyUnit : -1e30f;
-        mkey[(size_t)f * capP + i] = k;
-        // the register-streamed kernel (match_mfma2_kernel) loads the accumulator-init tuple {k, k, k, k} of its column with
-        // one 16-byte load
-        mkey4[(size_t)f * capP + i] = make_float4(k, k, k, k);
-    }
+    if (w == 0) mkey[(size_t)f * capP + i] = live ? -(float)(pop * kMmaS + i) * kKeyUnit : -1e30f;
 }
 
 // RB = query row blocks of 16 per workgroup: 8 (128 queries), or 4 when the call is so small that 128-query
@@ -252,216 +247,54 @@ match_mfma_kernel(const uint4 *__restrict__ mexp, const float *__restrict__ mkey
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Round 5: the same product with the candidate blocks streamed through REGISTERS and the epilogue UNDER the MFMAs.
+// (3) match_tile_kernel (round 5): the block tile that expands its own operands -- what large calls run.
 //
-// What round 4's counters said about match_mfma_kernel: 512 MFMAs x 16 cycles + 856 other vector instructions x ~4.6 =
-// the 12 200 cycles a wave takes -- the two kinds of work add, they do not overlap (the 0.156 "co-execution" the counter
-// shows is the MFMAs' own issue cycles).  A 16-cycle MFMA holds the SIMD's vector issue for 8 of its 16 cycles
-// (MI355X_MICROARCH.md, row 'vector-instruction ISSUE cost'); a v_max3_f32 costs 4: one fold per MFMA FITS in the gap -- if it
-// is an independent instruction that sits right behind the MFMA in the SAME wave's stream.  In the round-4 loop the four
-// folds of a row block came after its four MFMAs and depended on them, so every wave alternated "wait for the pipe" with
-// "fold", and three such waves per SIMD queued on the matrix pipe instead of filling each other's gaps.
-// Here the stream is software-pipelined by one row block: MFMA (block m), fold (block m - 1), MFMA, fold, ... pinned with
-// sched_group_barrier, the last block's folds carried into the next step.  And the candidate fragments no longer pass
-// through LDS: the fragment image written by match_expand_kernel is lane-linear, so a plain 16-byte global load per lane
-// IS the B operand -- no LDS-DMA, no M0 writes, no ds_read, no counted vmcnt by hand (hipcc counts plain loads itself);
-// the ring is three register slots of two blocks, filled two steps ahead.
-// Same arithmetic, same keys, same reduction through LDS at the end: bit-identical results (the 111 matcher tests).
-template <int RB, int NW, int WPE>
-__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
-match_mfma2_kernel(const uint4 *__restrict__ mexp, const float *__restrict__ mkey, const float4 *__restrict__ mkey4,
-                   const int32_t *__restrict__ counts, int cap, int capP, int first, int stride, int max_dist,
-                   int32_t *__restrict__ out_idx, int32_t *__restrict__ out_dist)
-{
-    constexpr int kMmaLds = mma_lds_row(NW);
-    constexpr int kMmaRows = 16 * RB;
-    __shared__ __attribute__((aligned(16))) float s_best[kMmaRows * kMmaLds];
-    int pk, blk;
-    xcd_remap(gridDim.x, gridDim.y, &pk, &blk); // all query blocks of a pair share one L2
-    const int p = first + pk * stride;
-    const int nA = clamp_count(counts[p], cap), nB = clamp_count(counts[p + 1], cap);
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int row0 = blk * kMmaRows;
-    const uint4 *__restrict__ Ea = mexp + (size_t)p * capP * 8;
-    const uint4 *__restrict__ Eb = mexp + (size_t)(p + 1) * capP * 8;
-    const float4 *__restrict__ Kb = mkey4 + (size_t)(p + 1) * capP;
-    const bool active = row0 < nA && nB > 0; // block-uniform
-
-    if (active) {
-        v8i a[RB][2];
-#pragma unroll
-        for (int m = 0; m < RB; m++) {
-            const int ab = (row0 >> 4) + m;
-            const bool in = ab * 16 < capP;
-#pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
-                const uint4 q = in ? Ea[(size_t)ab * 128 + ks * 64 + lane] : make_uint4(0, 0, 0, 0);
-                a[m][ks] = (v8i){(int)q.x, (int)q.y, (int)q.z, (int)q.w, 0, 0, 0, 0};
-            }
-        }
-        v4f best[RB];
-#pragma unroll
-        for (int m = 0; m < RB; m++) best[m] = (v4f){-3e38f, -3e38f, -3e38f, -3e38f};
-        const int nBb = (nB + 15) >> 4;
-        const int T = wv < nBb ? (nBb - wv + NW - 1) / NW : 0; // candidate blocks of this wave: wv, wv + NW, ...
-        const int S = (T + 1) >> 1;                               // steps of two blocks
-        struct Blk {
-            uint4 b0, b1; // the two k-steps of the fragment
-            float4 k;     // the column key, four times: the accumulator-init tuple
-        };
-        // a block past the wave's last one is the clamped last block again: maxima are idempotent
-        // buffer loads: the frame's fragment image and its key tuples behind two 128-bit descriptors, the block as the
-        // instruction's SCALAR offset, the lane as a constant 32-bit vector offset -- no address arithmetic on the vector ALU
-        const __amdgpu_buffer_rsrc_t rE = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(Eb), 0, capP * 128, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(Kb), 0, capP * 16, 0x00020000);
-        const int lane16 = lane * 16, col16 = (lane & 15) * 16;
-        const int diag_nb = max_dist < -1000 ? 1 : nBb; // TEMPORARY diagnostic
-        auto load = [&](int t) {
-            int lb = wv + NW * t;
-            lb = lb < diag_nb ? lb : diag_nb - 1;
-            Blk r;
-            r.b0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rE, lane16, lb * 2048, 0));
-            r.b1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rE, lane16 + 1024, lb * 2048, 0));
-            r.k = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rK, col16, lb * 256, 0));
-            return r;
-        };
-        // the two row blocks whose folds are still owed: the fold of block m - 2 sits under the MFMAs of block m (one block
-        // of lag is not enough: its last MFMA would be the instruction right in front of the fold that reads it)
-        const v4f kLow = (v4f){-3e38f, -3e38f, -3e38f, -3e38f};
-        v4f p1c = kLow, p1d = kLow, p2c = kLow, p2d = kLow;
-        // SPREAD: the six loads that refill slot (N0, N1) go out one per row block instead of six in a row
-        auto step = [&](const Blk &X, const Blk &Y, Blk *N0, Blk *N1, int tn) {
-            int lbn0 = wv + NW * tn, lbn1 = wv + NW * (tn + 1);
-            lbn0 = lbn0 < nBb ? lbn0 : nBb - 1;
-            lbn1 = lbn1 < nBb ? lbn1 : nBb - 1;
-            const v8i b0 = (v8i){(int)X.b0.x, (int)X.b0.y, (int)X.b0.z, (int)X.b0.w, 0, 0, 0, 0};
-            const v8i b1 = (v8i){(int)X.b1.x, (int)X.b1.y, (int)X.b1.z, (int)X.b1.w, 0, 0, 0, 0};
-            const v8i d0 = (v8i){(int)Y.b0.x, (int)Y.b0.y, (int)Y.b0.z, (int)Y.b0.w, 0, 0, 0, 0};
-            const v8i d1 = (v8i){(int)Y.b1.x, (int)Y.b1.y, (int)Y.b1.z, (int)Y.b1.w, 0, 0, 0, 0};
-            const v4f cv = (v4f){X.k.x, X.k.y, X.k.z, X.k.w}, dv = (v4f){Y.k.x, Y.k.y, Y.k.z, Y.k.w};
-#pragma unroll
-            for (int m = 0; m < RB; m++) {
-                v4f &fold = best[(m + RB - 2) % RB]; // m = 0, 1: the previous step's last two row blocks
-                // cbsz = blgp = 4: e2m1 operands; scale arguments 0, 0 select the unscaled instruction
-                v4f acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m][0], b0, cv, 4, 4, 0, 0, 0, 0);
-                fold[0] = __builtin_fmaxf(__builtin_fmaxf(fold[0], p2c[0]), p2d[0]); // v_max3_f32
-                v4f acd = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m][0], d0, dv, 4, 4, 0, 0, 0, 0);
-                fold[1] = __builtin_fmaxf(__builtin_fmaxf(fold[1], p2c[1]), p2d[1]);
-                acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m][1], b1, acc, 4, 4, 0, 0, 0, 0);
-                fold[2] = __builtin_fmaxf(__builtin_fmaxf(fold[2], p2c[2]), p2d[2]);
-                acd = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m][1], d1, acd, 4, 4, 0, 0, 0, 0);
-                fold[3] = __builtin_fmaxf(__builtin_fmaxf(fold[3], p2c[3]), p2d[3]);
-                p2c = p1c;
-                p2d = p1d;
-                p1c = acc;
-                p1d = acd;
-                // the emitted order: one matrix instruction, one vector instruction, four times
-#pragma unroll
-                for (int g4 = 0; g4 < 4; g4++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0); // VALU
-                }
-                if (N0) {
-                    if (m == 0) N0->b0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rE, lane16, lbn0 * 2048, 0));
-                    if (m == 1) N0->b1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rE, lane16 + 1024, lbn0 * 2048, 0));
-                    if (m == 2) N0->k = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rK, col16, lbn0 * 256, 0));
-                    if (m == 3) N1->b0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rE, lane16, lbn1 * 2048, 0));
-                    if (m == 4) N1->b1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rE, lane16 + 1024, lbn1 * 2048, 0));
-                    if (m == 5) N1->k = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rK, col16, lbn1 * 256, 0));
-                }
-                // ... and nothing crosses from one row block to the next: each is scheduled on its own (left free, the
-                // scheduler lets the pattern decay over a three-step loop body)
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        // three register slots of two blocks each, filled two steps ahead; whole groups of three steps first (no exit
-        // inside the loop: the compiler then counts the outstanding loads itself, vmcnt(n) at the first use of a slot)
-        Blk s0a = load(0), s0b = load(1), s1a = load(2), s1b = load(3), s2a, s2b;
-        int i = 0;
-        if (max_dist < -3000) { // TEMPORARY diagnostic: no loads inside the loop at all
-            s2a = load(4);
-            s2b = load(5);
-            for (; i + 3 <= S; i += 3) {
-                step(s0a, s0b, nullptr, nullptr, 0);
-                step(s1a, s1b, nullptr, nullptr, 0);
-                step(s2a, s2b, nullptr, nullptr, 0);
-            }
-        }
-        for (; i + 3 <= S; i += 3) {
-            step(s0a, s0b, &s2a, &s2b, 2 * i + 4);
-            step(s1a, s1b, &s0a, &s0b, 2 * i + 6);
-            step(s2a, s2b, &s1a, &s1b, 2 * i + 8);
-        }
-        if (i < S) step(s0a, s0b, nullptr, nullptr, 0);     // the remaining one or two steps: their blocks are already in flight
-        if (i + 1 < S) step(s1a, s1b, nullptr, nullptr, 0);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            best[RB - 2][r] = __builtin_fmaxf(__builtin_fmaxf(best[RB - 2][r], p2c[r]), p2d[r]);
-            best[RB - 1][r] = __builtin_fmaxf(__builtin_fmaxf(best[RB - 1][r], p1c[r]), p1d[r]);
-        }
-        // C/D layout: lane holds rows 4 * (lane >> 4) + r of each 16-row fragment, column lane & 15
-#pragma unroll
-        for (int m = 0; m < RB; m++)
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-                s_best[(m * 16 + 4 * (lane >> 4) + r) * kMmaLds + wv * 16 + (lane & 15)] = best[m][r];
-    }
-    __syncthreads();
-    constexpr int kTPR = NW >= 4 ? 2 : 1, kFPT = 16 * NW / kTPR, kRowStep = 64 * NW / kTPR;
-    for (int row = (int)threadIdx.x / kTPR; row < kMmaRows; row += kRowStep) {
-        const int part = (int)threadIdx.x % kTPR;
-        float v = -3e38f;
-        if (active) {
-            const float4 *src = reinterpret_cast<const float4 *>(s_best + row * kMmaLds + part * kFPT);
-#pragma unroll
-            for (int k = 0; k < kFPT / 4; k++) {
-                const float4 x = src[k];
-                v = fmaxf(fmaxf(v, fmaxf(x.x, x.y)), fmaxf(x.z, x.w));
-            }
-        }
-        if (kTPR == 2) v = fmaxf(v, __shfl_xor(v, 1));
-        const int i = row0 + row;
-        if (part == 0 && i < cap) {
-            bool ok = active && i < nA && v > -1e29f;
-            int bj = -1, bd = -1;
-            if (ok) {
-                const int nk = -(int)(v * (2 * kMmaS));                                       // S * (dist - |a_i|) + j
-                const int pop_a = (-(int)(mkey[(size_t)p * capP + i] * (2 * kMmaS))) >> 14; // |a_i|
-                bj = nk & (kMmaS - 1);
-                bd = pop_a + (nk >> 14);
-                ok = bd <= max_dist;
-            }
-            out_idx[(size_t)pk * cap + i] = ok ? bj : -1;
-            if (out_dist) out_dist[(size_t)pk * cap + i] = ok ? bd : -1;
-        }
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Round 5, second form: the block tile.  match_mfma2_kernel showed (tools/r5_match_diag.py) that with the folds under the
-// MFMAs the loop reaches the matrix pipe's pace when the candidate operands are free (0.85 ms per 4096 frames), and that
-// what it pays on top -- 0.35 ms -- is the ISSUE of its six 1-KB vector loads per step, the same whether they hit L1 or L2.
-// Every wave of a workgroup streamed the whole candidate frame for itself.  Here the four waves of a workgroup hold
-// DIFFERENT queries (4 x 128 = 512 per workgroup) and consume the SAME candidate blocks: one ring of three slots in LDS,
-// filled by LDS-DMA -- each wave brings a quarter of a step's fragments -- and read by all four with ds_read_b128.  Vector
-// memory instructions per MFMA fall to a quarter (and L2 -> CU traffic with them); a wave's partial maxima never leave it
-// (16 column classes met by four lane shuffles at the end), so there is no cross-wave reduction through LDS either.
-// One s_barrier per step orders both directions: a wave passes it only after ITS pieces of this step have landed
-// (vmcnt) and after it has consumed the previous step's slot, so behind the barrier the slot of this step is complete and
-// the slot of the step before may be refilled.  Same keys, same folds: bit-identical results.
-constexpr int kTileRing = 3;                     // slots; a slot = one step = four candidate blocks
-constexpr int kTileBlk = 2048 + 256;             // fragment image + 16 keys x 4 copies
+// What round 4's counters said about match_mfma_kernel: 512 MFMAs x 16 cycles + 856 other vector instructions x ~4.6 are
+// the 12 200 cycles a wave takes; the two kinds of work ADD (the 0.156 "co-execution" its counter shows is the MFMAs' own
+// issue cycles).  tools/mfma_fold_probe.hip measures what the chip allows: in one wave's stream an MFMA followed by an
+// INDEPENDENT v_max3_f32 costs 19 cycles against 18 for the bare MFMA (two folds: 19.5) -- a 16-cycle MFMA holds the
+// SIMD's vector issue for only part of its time (MI355X_MICROARCH.md, row 'vector-instruction ISSUE cost').  In the
+// round-4 loop the four folds of a row block came right behind its four MFMAs and depended on them, so a wave alternated
+// "wait for the pipe" with "fold" and three such waves per SIMD queued on the matrix pipe.  Three changes, each measured
+// (tools/experiments/README.md, matcher_forms.patch keeps the two intermediate kernels):
+//  a. the folds are software-pipelined by TWO row blocks (one is not enough: the fold would read the MFMA issued right in
+//     front of it) and the order MFMA, fold, MFMA, fold is pinned -- sched_group_barrier per instruction pair,
+//     sched_barrier per row block; left free, hipcc's scheduler lets the pattern decay over an unrolled loop body;
+//  b. with a. the loop runs at the matrix pipe's pace when its operands are free (0.85 ms per 4096 frames) and pays
+//     0.35 ms for the ISSUE of the six 1-KB vector loads a wave needs per 32 MFMAs, L1 hit or not (every wave streamed the
+//     whole candidate frame for itself: 36 B per cycle and CU against the L1's 64).  So the four waves of a workgroup hold
+//     DIFFERENT queries (4 x 128 = 512 per workgroup) and consume the SAME candidate blocks from a ring in LDS: vector
+//     memory instructions and L2 -> CU bytes per MFMA fall to a quarter; a wave's partial maxima never leave it (16 column
+//     classes met by four lane shuffles at the end), so there is no cross-wave reduction either;
+//  c. every candidate block now enters a workgroup ONCE, so the workgroup can afford to build it: match_expand_kernel's
+//     e2m1 scratch (128 B + a key per keypoint, written once and read as the A and as the B operand: the stage moved 5.2 x
+//     its algorithmic bytes, and the kernel was 0.29 ms of every step) is not used.  Wave w takes block w of a step --
+//     two dwords of descriptor per lane (lane L: words L >> 4 and (L >> 4) + 4 of keypoint L & 15, exactly the fragment
+//     entries [k-step 0 / 1][lane L]), eight 8-bit -> 8-nibble spreads riding in the MFMA gaps next to the folds, the
+//     popcount for the column key met by two lane shuffles -- and writes fragment image and key tuples into the ring with
+//     ds_write_b128.  The queries are expanded the same way in the prologue.  No LDS-DMA, no scratch: 32 bytes of HBM
+//     traffic per keypoint and workgroup instead of 128 + 128 per keypoint and call plus the scratch's own round trip.
+// The ring has two slots of four blocks.  A slot is written one step after its last read and read one step after that;
+// ONE s_barrier per step, in the middle, orders both (see `step`).  All LDS traffic of the loop is hand-written asm: the
+// compiler must neither wait for the prefetched global loads at a barrier nor reorder the ring's reads and writes.  (And
+// no divergent branch in the loop: an `if (lane < 16)` around the key store split the body into blocks and cost 335
+// spilled registers; the four lanes of a keypoint hold the same key and all write it.)
+// Same keys, same folds, same winner: bit-identical to the other forms and to the oracle (the 111 matcher tests run on
+// every form).  Measured: match stage 1.654 -> 1.522 ms per 4096 frames, step 5.99 -> 5.79 ms.
+constexpr int kTileBlk = 2048 + 256; // one candidate block in the ring: fragment image + 16 keys x 4 copies
 constexpr int kTileSlot = 4 * kTileBlk;
-template <int WPE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
-match_mfma3_kernel(const uint4 *__restrict__ mexp, const float *__restrict__ mkey, const int32_t *__restrict__ counts,
-                   int cap, int capP, int first, int stride, int max_dist, int32_t *__restrict__ out_idx,
-                   int32_t *__restrict__ out_dist)
+__device__ __forceinline__ u32x4 spread_word_e2m1(uint32_t w)
+{
+    return (u32x4){spread_bits_e2m1(w), spread_bits_e2m1(w >> 8), spread_bits_e2m1(w >> 16), spread_bits_e2m1(w >> 24)};
+}
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+match_tile_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *__restrict__ counts, int cap, int first,
+                   int stride, int max_dist, int32_t *__restrict__ out_idx, int32_t *__restrict__ out_dist)
 {
     constexpr int RB = 8;
-    __shared__ __attribute__((aligned(16))) unsigned char s_ring[kTileRing * kTileSlot];
+    constexpr int kRing2 = 2;
+    __shared__ __attribute__((aligned(16))) unsigned char s_ring[kRing2 * kTileSlot];
+    __shared__ uint16_t s_popA[512]; // |a| of the workgroup's queries (0..256)
     int pk, blk;
     xcd_remap(gridDim.x, gridDim.y, &pk, &blk); // all query tiles of a pair share one L2
     const int p = first + pk * stride;
@@ -469,63 +302,91 @@ match_mfma3_kernel(const uint4 *__restrict__ mexp, const float *__restrict__ mke
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int row0 = blk * 512 + wv * 128; // this wave's 128 queries
-    const uint4 *__restrict__ Ea = mexp + (size_t)p * capP * 8;
-    const uint4 *__restrict__ Eb = mexp + (size_t)(p + 1) * capP * 8;
-    const float *__restrict__ Kb = mkey + (size_t)(p + 1) * capP;
-    if (!(blk * 512 < nA && nB > 0)) { // workgroup-uniform: nothing to match
+    if (!(blk * 512 < nA && nB > 0)) {     // workgroup-uniform: nothing to match
         for (int i = blk * 512 + (int)threadIdx.x; i < blk * 512 + 512 && i < cap; i += 256) {
             out_idx[(size_t)pk * cap + i] = -1;
             if (out_dist) out_dist[(size_t)pk * cap + i] = -1;
         }
         return;
     }
+    // descriptor word `w` of record `kp` of frame f (the record is 13 dwords, the descriptor its dwords 5..12)
+    const uint32_t *__restrict__ recA = reinterpret_cast<const uint32_t *>(records + (size_t)p * cap);
+    const uint32_t *__restrict__ recB = reinterpret_cast<const uint32_t *>(records + (size_t)(p + 1) * cap);
+    const int kq = lane & 15, wq = lane >> 4;
     v8i a[RB][2];
-#pragma unroll
-    for (int m = 0; m < RB; m++) {
-        const int ab = (row0 >> 4) + m;
-        const bool in = ab * 16 < capP;
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            const uint4 q = in ? Ea[(size_t)ab * 128 + ks * 64 + lane] : make_uint4(0, 0, 0, 0);
-            a[m][ks] = (v8i){(int)q.x, (int)q.y, (int)q.z, (int)q.w, 0, 0, 0, 0};
-        }
-    }
     v4f best[RB];
-#pragma unroll
-    for (int m = 0; m < RB; m++) best[m] = (v4f){-3e38f, -3e38f, -3e38f, -3e38f};
     const int nBb = (nB + 15) >> 4;
     const int S = (nBb + 3) >> 2; // steps of four blocks, the same for every wave
     const uint32_t ring_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)s_ring;
     const uint32_t lds16 = ring_lds + lane * 16, ldsk = ring_lds + (lane & 15) * 16; // this lane's read addresses
-    const uint32_t lane_off16 = (uint32_t)lane * 16u, lane_off4 = (uint32_t)(lane >> 2) * 4u;
-    // this wave's three pieces of step t: block wv of the step -- its two k-steps and its keys.  Every wave has exactly
-    // three DMAs per step in flight, so one counted wait serves all.
-    auto issue = [&](int slot, int t) {
+    // this wave's source of step t: block 4 t + w of the candidate frame, two descriptor words per lane
+    struct Src {
+        uint32_t w0, w1;
+        int kp; // candidate index, or -1 past the count (key -1e30: never wins)
+    };
+    auto fetch = [&](int t) {
         int lb = 4 * t + wv;
         lb = lb < nBb ? lb : nBb - 1; // past the end: the last block again (maxima are idempotent)
-        unsigned char *dst = s_ring + slot * kTileSlot + wv * kTileBlk;
-        const char *src = reinterpret_cast<const char *>(Eb + (size_t)lb * 128) + lane_off16;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)dst, 16, 1024, 0); // (the offset moves both sides)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(Kb + lb * 16) + lane_off4),
-                                         (__attribute__((address_space(3))) void *)(dst + 2048), 4, 0, 0);
+        const int kp = lb * 16 + kq;
+        const int kc = kp < nB ? kp : nB - 1; // (nB >= 1 here) a legal record for the load; the key marks it dead
+        Src r;
+        r.w0 = recB[(size_t)kc * 13 + 5 + wq];
+        r.w1 = recB[(size_t)kc * 13 + 9 + wq];
+        r.kp = kp < nB ? kp : -1;
+        return r;
+    };
+    // the expansion of a source, in pieces a row block's scheduling region can take one at a time
+    struct Exp {
+        u32x4 f0, f1;
+        float key;
+    };
+    // fragment image + key tuples of this wave's block into slot `s` (all LDS traffic of the loop is hand-written: the
+    // compiler must neither wait for the prefetched global loads at a barrier nor reorder reads and writes of the ring)
+    auto store = [&](auto slot_c, const Exp &e) {
+        constexpr int sl = decltype(slot_c)::value;
+        const uint32_t base = lds16 + (uint32_t)(sl * kTileSlot) + (uint32_t)wv * kTileBlk;
+        const uint32_t kbase = ldsk + (uint32_t)(sl * kTileSlot) + (uint32_t)wv * kTileBlk;
+        const v4f k4 = (v4f){e.key, e.key, e.key, e.key};
+        // the key tuple: the four lanes of a keypoint hold the same key and write it to the same 16 bytes -- no branch (a
+        // divergent `if (lane < 16)` here split the loop body into blocks and cost the kernel 335 spilled registers)
+        asm volatile("ds_write_b128 %0, %2\n\tds_write_b128 %0, %3 offset:1024\n\tds_write_b128 %1, %4 offset:2048" ::"v"(base), "v"(kbase),
+                     "v"(e.f0), "v"(e.f1), "v"(k4)
+                     : "memory");
+    };
+    struct Ops {
+        u32x4 q0, q1, r0, r1;
+        v4f cv, dv;
+    };
+    auto read2 = [](auto off_c, Ops &o, uint32_t lds16, uint32_t ldsk) {
+        constexpr int off = decltype(off_c)::value;
+        asm volatile("ds_read_b128 %0, %6 offset:%8\n\tds_read_b128 %1, %6 offset:%9\n\t"
+                     "ds_read_b128 %2, %7 offset:%10\n\t"
+                     "ds_read_b128 %3, %6 offset:%11\n\tds_read_b128 %4, %6 offset:%12\n\t"
+                     "ds_read_b128 %5, %7 offset:%13"
+                     : "=&v"(o.q0), "=&v"(o.q1), "=&v"(o.cv), "=&v"(o.r0), "=&v"(o.r1), "=&v"(o.dv)
+                     : "v"(lds16), "v"(ldsk), "n"(off), "n"(off + 1024), "n"(off + 2048), "n"(off + kTileBlk),
+                       "n"(off + kTileBlk + 1024), "n"(off + kTileBlk + 2048)
+                     : "memory");
+    };
+    auto landed = [](Ops &o) { // the wait is tied to the registers, so nothing reads (or copies) them before it
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o.q0), "+v"(o.q1), "+v"(o.cv), "+v"(o.r0), "+v"(o.r1), "+v"(o.dv)::"memory");
     };
     const v4f kLow = (v4f){-3e38f, -3e38f, -3e38f, -3e38f};
-    v4f p1c = kLow, p1d = kLow, p2c = kLow, p2d = kLow; // the two row blocks whose folds are still owed (match_mfma2_kernel)
-    // 32 MFMAs over two candidate blocks with the folds of two row blocks ago between them
-    auto mma2 = [&](const u32x4 &q0, const u32x4 &q1, const v4f &cv, const u32x4 &r0, const u32x4 &r1, const v4f &dv) {
-        const v8i b0 = (v8i){(int)q0.x, (int)q0.y, (int)q0.z, (int)q0.w, 0, 0, 0, 0};
-        const v8i b1 = (v8i){(int)q1.x, (int)q1.y, (int)q1.z, (int)q1.w, 0, 0, 0, 0};
-        const v8i d0 = (v8i){(int)r0.x, (int)r0.y, (int)r0.z, (int)r0.w, 0, 0, 0, 0};
-        const v8i d1 = (v8i){(int)r1.x, (int)r1.y, (int)r1.z, (int)r1.w, 0, 0, 0, 0};
+    v4f p1c = kLow, p1d = kLow, p2c = kLow, p2d = kLow; // the two row blocks whose folds are still owed
+    // 32 MFMAs over two candidate blocks with the folds of two row blocks ago between them and (EXPAND) one spread of the
+    // next source block per row block: the pattern is then one matrix + up to three vector instructions
+    auto mma2 = [&](auto expand_c, const Ops &o, const Src &sr, Exp &ex) {
+        constexpr bool kExpand = decltype(expand_c)::value;
+        const v8i b0 = (v8i){(int)o.q0.x, (int)o.q0.y, (int)o.q0.z, (int)o.q0.w, 0, 0, 0, 0};
+        const v8i b1 = (v8i){(int)o.q1.x, (int)o.q1.y, (int)o.q1.z, (int)o.q1.w, 0, 0, 0, 0};
+        const v8i d0 = (v8i){(int)o.r0.x, (int)o.r0.y, (int)o.r0.z, (int)o.r0.w, 0, 0, 0, 0};
+        const v8i d1 = (v8i){(int)o.r1.x, (int)o.r1.y, (int)o.r1.z, (int)o.r1.w, 0, 0, 0, 0};
 #pragma unroll
         for (int m = 0; m < RB; m++) {
             v4f &fold = best[(m + RB - 2) % RB]; // m = 0, 1: the previous pass's last two row blocks
-            v4f acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m][0], b0, cv, 4, 4, 0, 0, 0, 0);
+            v4f acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m][0], b0, o.cv, 4, 4, 0, 0, 0, 0);
             fold[0] = __builtin_fmaxf(__builtin_fmaxf(fold[0], p2c[0]), p2d[0]); // v_max3_f32
-            v4f acd = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m][0], d0, dv, 4, 4, 0, 0, 0, 0);
+            v4f acd = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m][0], d0, o.dv, 4, 4, 0, 0, 0, 0);
             fold[1] = __builtin_fmaxf(__builtin_fmaxf(fold[1], p2c[1]), p2d[1]);
             acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m][1], b1, acc, 4, 4, 0, 0, 0, 0);
             fold[2] = __builtin_fmaxf(__builtin_fmaxf(fold[2], p2c[2]), p2d[2]);
@@ -535,58 +396,95 @@ match_mfma3_kernel(const uint4 *__restrict__ mexp, const float *__restrict__ mke
             p2d = p1d;
             p1c = acc;
             p1d = acd;
+            if (kExpand) { // spread number m of the eight
+                const uint32_t w = m < 4 ? sr.w0 : sr.w1;
+                const uint32_t v = spread_bits_e2m1(w >> (8 * (m & 3)));
+                if (m == 0) ex.f0.x = v;
+                if (m == 1) ex.f0.y = v;
+                if (m == 2) ex.f0.z = v;
+                if (m == 3) ex.f0.w = v;
+                if (m == 4) ex.f1.x = v;
+                if (m == 5) ex.f1.y = v;
+                if (m == 6) ex.f1.z = v;
+                if (m == 7) ex.f1.w = v;
+            }
 #pragma unroll
-            for (int g4 = 0; g4 < 4; g4++) { // the emitted order: one matrix instruction, one vector instruction, four times
+            for (int g4 = 0; g4 < 4; g4++) { // the emitted order: one matrix instruction, then the vector instructions due
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, kExpand ? 2 : 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0); // nothing crosses from one row block to the next
         }
     };
+    // the expansion of a source block: eight 8-bit -> 8-nibble spreads, the popcount met across the four lanes of a keypoint
+    auto expand = [&](const Src &sr) {
+        Exp e;
+        e.f0 = spread_word_e2m1(sr.w0);
+        e.f1 = spread_word_e2m1(sr.w1);
+        int pc = __popc(sr.w0) + __popc(sr.w1);
+        pc += __shfl_xor(pc, 16);
+        pc += __shfl_xor(pc, 32);
+        e.key = sr.kp >= 0 ? -(float)(pc * kMmaS + sr.kp) * kKeyUnit : -1e30f;
+        return e;
+    };
+    auto expand_key = [&](const Src &sr) {
+        int pc = __popc(sr.w0) + __popc(sr.w1);
+        pc += __shfl_xor(pc, 16);
+        pc += __shfl_xor(pc, 32);
+        return sr.kp >= 0 ? -(float)(pc * kMmaS + sr.kp) * kKeyUnit : -1e30f;
+    };
+    Ops P, Q;
+    Exp E;
+    // prologue: steps 0 and 1 expanded into the two slots, the sources of steps 2 and 3 requested
+    store(std::integral_constant<int, 0>{}, expand(fetch(0)));
+    store(std::integral_constant<int, 1>{}, expand(fetch(1)));
+    Src nx0 = fetch(2), nx1 = fetch(3);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    read2(std::integral_constant<int, 0>{}, P, lds16, ldsk);
+    // the queries' fragments, expanded here (AFTER the ring's prologue: their 64 registers start to live only now)
+#pragma unroll
+    for (int m = 0; m < RB; m++) {
+        const int kp = row0 + m * 16 + kq;
+        const bool in = kp < nA; // (rows past the count: zero fragments, results discarded below)
+        const uint32_t w0 = in ? recA[(size_t)kp * 13 + 5 + wq] : 0u, w1 = in ? recA[(size_t)kp * 13 + 9 + wq] : 0u;
+        const u32x4 f0 = spread_word_e2m1(w0), f1 = spread_word_e2m1(w1);
+        a[m][0] = (v8i){(int)f0.x, (int)f0.y, (int)f0.z, (int)f0.w, 0, 0, 0, 0};
+        a[m][1] = (v8i){(int)f1.x, (int)f1.y, (int)f1.z, (int)f1.w, 0, 0, 0, 0};
+        int pc = __popc(w0) + __popc(w1);
+        pc += __shfl_xor(pc, 16);
+        pc += __shfl_xor(pc, 32);
+        if (wq == 0) s_popA[wv * 128 + m * 16 + kq] = (uint16_t)pc;
+    }
+#pragma unroll
+    for (int m = 0; m < RB; m++) best[m] = (v4f){-3e38f, -3e38f, -3e38f, -3e38f};
+    // One step = slot s = four candidate blocks and ONE barrier, in the middle: by then this wave holds every operand of the
+    // slot in registers (and its own ring writes of the step before have completed: the same lgkmcnt(0)), so behind the
+    // barrier slot s may take step t + 2, and the other slot, written a step ago, is complete for everybody.  Both halves'
+    // LDS reads are requested 32 MFMAs before they are needed; the expansion rides in the first half's MFMA gaps.
     auto step = [&](auto slot_c, int t) {
         constexpr int s = decltype(slot_c)::value;
-        // my pieces of this step have landed (three younger DMAs may still be in flight: the next step's); then everybody's
-        asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
-        issue((s + 2) % kTileRing, t + 2); // refills the slot the previous step read: every wave is past those reads
-        u32x4 q0, q1, r0, r1, u0, u1, w0, w1;
-        v4f cv, dv, ev, fv;
-        // hand-written reads: hipcc would put its own vmcnt(0) in front of a compiler-visible LDS read that may alias a DMA.
-        // Blocks 0, 1 are waited for; the reads of blocks 2, 3 stay in flight under the first 32 MFMAs.
-        asm volatile("ds_read_b128 %0, %6 offset:%8\n\tds_read_b128 %1, %6 offset:%9\n\t"
-                     "ds_read_b128 %2, %7 offset:%10\n\t"
-                     "ds_read_b128 %3, %6 offset:%11\n\tds_read_b128 %4, %6 offset:%12\n\t"
-                     "ds_read_b128 %5, %7 offset:%13\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(q0), "=&v"(q1), "=&v"(cv), "=&v"(r0), "=&v"(r1), "=&v"(dv)
-                     : "v"(lds16), "v"(ldsk), "n"(s * kTileSlot), "n"(s * kTileSlot + 1024), "n"(s * kTileSlot + 2048),
-                       "n"(s * kTileSlot + kTileBlk), "n"(s * kTileSlot + kTileBlk + 1024), "n"(s * kTileSlot + kTileBlk + 2048)
-                     : "memory");
-        asm volatile("ds_read_b128 %0, %6 offset:%8\n\tds_read_b128 %1, %6 offset:%9\n\t"
-                     "ds_read_b128 %2, %7 offset:%10\n\t"
-                     "ds_read_b128 %3, %6 offset:%11\n\tds_read_b128 %4, %6 offset:%12\n\t"
-                     "ds_read_b128 %5, %7 offset:%13"
-                     : "=&v"(u0), "=&v"(u1), "=&v"(ev), "=&v"(w0), "=&v"(w1), "=&v"(fv)
-                     : "v"(lds16), "v"(ldsk), "n"(s * kTileSlot + 2 * kTileBlk), "n"(s * kTileSlot + 2 * kTileBlk + 1024),
-                       "n"(s * kTileSlot + 2 * kTileBlk + 2048), "n"(s * kTileSlot + 3 * kTileBlk),
-                       "n"(s * kTileSlot + 3 * kTileBlk + 1024), "n"(s * kTileSlot + 3 * kTileBlk + 2048)
-                     : "memory");
+        landed(P);                                                       // blocks 0, 1: requested in the previous step
+        read2(std::integral_constant<int, s * kTileSlot + 2 * kTileBlk>{}, Q, lds16, ldsk);
+        const Src cur = nx0; // the source of step t + 2, fetched two steps ago
+        nx0 = nx1;
+        nx1 = fetch(t + 4);
         __builtin_amdgcn_sched_barrier(0);
-        mma2(q0, q1, cv, r0, r1, dv);
-        // the second half's operands: the wait is tied to the registers, so nothing reads (or copies) them before it
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(u0), "+v"(u1), "+v"(ev), "+v"(w0), "+v"(w1), "+v"(fv)::"memory");
+        mma2(std::true_type{}, P, cur, E);
+        E.key = expand_key(cur);
+        landed(Q);
+        asm volatile("s_barrier" ::: "memory");
+        store(slot_c, E); // step t + 2 into the slot everybody has just finished with
+        read2(std::integral_constant<int, ((s + 1) % kRing2) * kTileSlot>{}, P, lds16, ldsk);
         __builtin_amdgcn_sched_barrier(0);
-        mma2(u0, u1, ev, w0, w1, fv);
+        mma2(std::false_type{}, Q, cur, E);
     };
-    issue(0, 0);
-    issue(1, 1);
     int i = 0;
-    for (; i + 3 <= S; i += 3) {
+    for (; i + 2 <= S; i += 2) {
         step(std::integral_constant<int, 0>{}, i);
         step(std::integral_constant<int, 1>{}, i + 1);
-        step(std::integral_constant<int, 2>{}, i + 2);
     }
     if (i < S) step(std::integral_constant<int, 0>{}, i); // S is the same for the four waves: the barriers stay matched
-    if (i + 1 < S) step(std::integral_constant<int, 1>{}, i + 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the clamped tail DMAs land before the workgroup's LDS is released
+    landed(P); // (the read of the slot after the last one: harmless, but it must have returned before the registers die)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         best[RB - 2][r] = __builtin_fmaxf(__builtin_fmaxf(best[RB - 2][r], p2c[r]), p2d[r]);
@@ -608,10 +506,9 @@ match_mfma3_kernel(const uint4 *__restrict__ mexp, const float *__restrict__ mke
                 bool ok = i_q < nA && v > -1e29f;
                 int bj = -1, bd = -1;
                 if (ok) {
-                    const int nk = -(int)(v * (2 * kMmaS));                                         // S * (dist - |a_i|) + j
-                    const int pop_a = (-(int)(mkey[(size_t)p * capP + i_q] * (2 * kMmaS))) >> 14; // |a_i|
+                    const int nk = -(int)(v * (2 * kMmaS)); // S * (dist - |a_i|) + j
                     bj = nk & (kMmaS - 1);
-                    bd = pop_a + (nk >> 14);
+                    bd = (int)s_popA[wv * 128 + m * 16 + 4 * (lane >> 4) + r] + (nk >> 14); // |a_i| from the prologue
                     ok = bd <= max_dist;
                 }
                 out_idx[(size_t)pk * cap + i_q] = ok ? bj : -1;
@@ -620,55 +517,31 @@ match_mfma3_kernel(const uint4 *__restrict__ mexp, const float *__restrict__ mke
         }
 }
 
+// Which form a call takes.  The tile kernel's workgroup holds 512 queries: a call needs at least one (pair, query tile)
+// item per CU, or the 128-query forms fill the chip better (bench.py --mode match, ORBFE_MATCH=stream | tile: 15 pairs of
+// 8192 keypoints = 240 items: 0.090 ms streamed against 0.112 tiled; 255 pairs of 2000 = 1020 items: 0.1037 against 0.1022;
+// 255 pairs of 405 = 255 items: 0.0221 against 0.0177 -- short loops favour the single launch).  form: 0 = by size, 1 = the expand + stream forms,
+// 2 = the tile form (ORBFE_MATCH=stream|tile, read when the context is created: A/B timing, and the tests run both).
+bool match_mfma_uses_tile(int n_pairs, int capP, int form)
+{
+    if (form == 1) return false;
+    if (form == 2) return true;
+    return (long long)n_pairs * ((capP + 511) / 512) >= 256;
+}
+
 void launch_match_mfma(const orbfe_keypoint *d_records, const int32_t *d_counts, int n_frames, int n_pairs, int first,
-                       int stride, int cap, int capP, int max_dist, uint4 *mexp, float *mkey, float4 *mkey4, int32_t *d_idx,
+                       int stride, int cap, int capP, int max_dist, uint4 *mexp, float *mkey, int form, int32_t *d_idx,
                        int32_t *d_dist, hipStream_t stream)
 {
     static_assert(kMmaS == kMmaMaxKeypoints, "key packing");
-    hipLaunchKernelGGL(match_expand_kernel, dim3((capP * 8 + 255) / 256, n_frames), dim3(256), 0, stream, d_records,
-                       d_counts, cap, capP, mexp, mkey, mkey4);
-    if (const char *v2 = getenv("ORBFE_MATCH_V2")) { // round-5 A/B: "<waves per workgroup><waves per SIMD>", e.g. 41, 42, 82
-        const dim3 grid((capP + 127) / 128, n_pairs);
-#define ORBFE_V2(NWV, WPEV)                                                                                              \
-    hipLaunchKernelGGL((match_mfma2_kernel<8, NWV, WPEV>), grid, dim3(64 * NWV), 0, stream, mexp, mkey, mkey4, d_counts, cap, \
-                       capP, first, stride, max_dist, d_idx, d_dist)
-        if (!strcmp(v2, "41")) { ORBFE_V2(4, 1); return; }
-        if (!strcmp(v2, "42")) { ORBFE_V2(4, 2); return; }
-        if (!strcmp(v2, "43")) { ORBFE_V2(4, 3); return; }
-        if (!strcmp(v2, "82")) { ORBFE_V2(8, 2); return; }
-        if (!strcmp(v2, "21")) { ORBFE_V2(2, 1); return; }
-        if (!strcmp(v2, "22")) { ORBFE_V2(2, 2); return; }
-#undef ORBFE_V2
-        if (v2[0] == 't') { // the block tile: t2 / t3 = waves per SIMD
-            const dim3 grid((capP + 511) / 512, n_pairs);
-            if (v2[1] == '3')
-                hipLaunchKernelGGL((match_mfma3_kernel<3>), grid, dim3(256), 0, stream, mexp, mkey, d_counts, cap, capP, first, stride,
-                                   max_dist, d_idx, d_dist);
-            else
-                hipLaunchKernelGGL((match_mfma3_kernel<2>), grid, dim3(256), 0, stream, mexp, mkey, d_counts, cap, capP, first, stride,
-                                   max_dist, d_idx, d_dist);
-            return;
-        }
-        // 192 queries per workgroup (12 row blocks): a third fewer candidate loads per MFMA, 2 waves per SIMD still fit
-        if (!strcmp(v2, "c22")) {
-            hipLaunchKernelGGL((match_mfma2_kernel<12, 2, 2>), dim3((capP + 191) / 192, n_pairs), dim3(128), 0, stream, mexp, mkey, mkey4,
-                               d_counts, cap, capP, first, stride, max_dist, d_idx, d_dist);
-            return;
-        }
-        if (!strcmp(v2, "c42")) {
-            hipLaunchKernelGGL((match_mfma2_kernel<12, 4, 2>), dim3((capP + 191) / 192, n_pairs), dim3(256), 0, stream, mexp, mkey, mkey4,
-                               d_counts, cap, capP, first, stride, max_dist, d_idx, d_dist);
-            return;
-        }
+    if (match_mfma_uses_tile(n_pairs, capP, form)) {
+        hipLaunchKernelGGL(match_tile_kernel, dim3((capP + 511) / 512, n_pairs), dim3(256), 0, stream, d_records, d_counts, cap,
+                           first, stride, max_dist, d_idx, d_dist);
+        return;
     }
-    const char *nw = getenv("ORBFE_MATCH_WAVES"); // "2": the 18 KB / 2-wave form (A/B and co-residency probes)
-    if (nw && nw[0] == '2')
-        hipLaunchKernelGGL((match_mfma_kernel<8, 2>), dim3((capP + 127) / 128, n_pairs), dim3(128), 0, stream, mexp, mkey,
-                           d_counts, cap, capP, first, stride, max_dist, d_idx, d_dist);
-    else if (nw && nw[0] == '1')
-        hipLaunchKernelGGL((match_mfma_kernel<8, 1>), dim3((capP + 127) / 128, n_pairs), dim3(64), 0, stream, mexp, mkey,
-                           d_counts, cap, capP, first, stride, max_dist, d_idx, d_dist);
-    else if ((long long)n_pairs * ((capP + 127) / 128) >= 256) // at least one 128-query workgroup per CU
+    hipLaunchKernelGGL(match_expand_kernel, dim3((capP * 8 + 255) / 256, n_frames), dim3(256), 0, stream, d_records,
+                       d_counts, cap, capP, mexp, mkey);
+    if ((long long)n_pairs * ((capP + 127) / 128) >= 256) // at least one 128-query workgroup per CU
         hipLaunchKernelGGL((match_mfma_kernel<8, 4>), dim3((capP + 127) / 128, n_pairs), dim3(256), 0, stream, mexp, mkey,
                            d_counts, cap, capP, first, stride, max_dist, d_idx, d_dist);
     else

@@ -167,8 +167,10 @@ struct SteerArgs {
 // (first + k * stride, first + k * stride + 1), results at k * cap
 constexpr int kMmaMaxKeypoints = 16384;
 void launch_match_mfma(const orbfe_keypoint *d_records, const int32_t *d_counts, int n_frames, int n_pairs, int first,
-                       int stride, int cap, int capP, int max_dist, uint4 *mexp, float *mkey, float4 *mkey4, int32_t *d_idx,
+                       int stride, int cap, int capP, int max_dist, uint4 *mexp, float *mkey, int form, int32_t *d_idx,
                        int32_t *d_dist, hipStream_t stream);
+// form: 0 = by call size, 1 = match_expand_kernel + match_mfma_kernel, 2 = match_tile_kernel (orbfe_ctx::match_form)
+bool match_mfma_uses_tile(int n_pairs, int capP, int form);
 
 // batch_kernels.hip: orbfe_detect of the stage API on the fused tile kernel (one launch for all levels,
 // scores also written to the caller's response maps); integer threshold, dword-aligned levels; corners are
@@ -250,7 +252,7 @@ struct orbfe_ctx {
     uint32_t *d_bd32 = nullptr;     // [max_batch][cap] reference-mode matcher: compressed 32-bit descriptors
     uint4 *d_mexp = nullptr;        // [max_batch][cap_pad][8]  MFMA matcher: descriptors as e2m1 fragments (cap <= 16384)
     float *d_mkey = nullptr;        // [max_batch][cap_pad]     MFMA matcher: -(popcount * 16384 + index)
-    float4 *d_mkey4 = nullptr;      // [max_batch][cap_pad]     ... the same key four times: one 16-byte load IS the accumulator-init tuple
+    int match_form = 0;             // 0: by call size; 1 / 2: forced by ORBFE_MATCH=stream / tile (match_mfma.hip)
     int cap_pad = 0;                // cap rounded up to 16
     int cellkey_clean = 0;          // frames whose cell keys the last pyramid build left cleared (0 once detect ran)
     hipStream_t clean_stream = nullptr;      // ... on this stream

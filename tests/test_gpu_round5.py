@@ -8,7 +8,11 @@
     librccl.so.1 (tests/fake_rccl): worker processes without torch, and examples/multi_gpu_port with both threads on device 0;
   * the stage boundary's holes: SUM_OF_ABS_DIFF_ALL and MAX_THRESHOLD of orbfe_fast_calc_corner_response (fast.cu:233-241,
     :256-283), the f-theta projection (cuda-align.cu:44-50, post_processing.cu:32-38), camera structs passed as DEVICE
-    pointers as the reference does (buildStream.cpp:391-393).
+    pointers as the reference does (buildStream.cpp:391-393);
+  * a11, EXT brute force: BOTH forms of the matrix-core matcher (ORBFE_MATCH=stream: match_expand_kernel + match_mfma_kernel;
+    tile: match_tile_kernel, which expands its own operands -- what calls with >= 256 (pair, 512-query tile) items take
+    by themselves) through every brute-force matcher test of the earlier rounds, plus a call large enough for the
+    size rule to pick the tile form on its own.
 The oracle is unpinned by the reference (it holds no tests); see oracle/orbfe_oracle.h."""
 import ctypes as C
 import json
@@ -466,3 +470,74 @@ def test_camera_structs_as_device_pointers(gpu, oracle_mod):
     Tc = (C.c_double * 16)(*T.T.reshape(-1))
     orbfe.check(L.orbfe_reproject_points(out.data_ptr(), o_pts.data_ptr(), m, Tc, as_i(d_oi), stream(torch)))
     np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32), oracle_mod.reproject_points(ref_pts, T, intr(oracle_mod, o)).view(np.uint32))
+
+
+# ------------------------------------------------------------------ a11 EXT: both forms of the matrix-core matcher
+@pytest.mark.parametrize("form", ["stream", "tile"])
+def test_matrix_core_matcher_forms_through_the_earlier_rounds_tests(gpu, oracle_mod, monkeypatch, form):
+    """ORBFE_MATCH (read when a context is created) forces one form of the 256-bit brute-force matcher.  Every brute-force
+    test of rounds 1-2 is run on each: extraction-made records with identical frames (ties to the lower index), crafted
+    records (random, duplicated, all-zero, all-one descriptors; counts 0 and 1; caps that are not multiples of 16; 38 row
+    blocks; three distance limits), ragged counts (every tail of the candidate ring), 16384 keypoints per frame (the
+    14-bit index), strided pair lists.  The default (by call size) picks the stream forms for all of these calls."""
+    import test_gpu_parity as t1
+    import test_gpu_round2 as t2
+    torch, orbfe = gpu
+    monkeypatch.setenv("ORBFE_MATCH", form)
+    probe = orbfe.Context(640, 480, cell=8, min_arc=9, max_features=2000, max_batch=4)
+    want = "match_tile_kernel" if form == "tile" else "match_expand_kernel+match_mfma_kernel"
+    assert probe.dispatch_info(4, 1, -1)["match"] == want
+    probe.close()
+    t1.test_match_batch(gpu, oracle_mod, 1, -1, 256)
+    for w, h, kw in [(100, 70, dict(cell=8)), (640, 480, dict(cell=32)), (640, 480, dict(cell=8, max_features=2000)), (640, 480, dict(cell=8))]:
+        for maxd in (256, 90, 0):
+            t1.test_match_batch_256_crafted_records(gpu, oracle_mod, w, h, kw, maxd)
+    for w, h, kw in [(100, 70, dict(cell=8)), (640, 480, dict(cell=16)), (640, 480, dict(cell=8, max_features=2000))]:
+        t1.test_match_batch_256_ragged_counts_fuzz(gpu, oracle_mod, w, h, kw)
+    t1.test_match_batch_256_at_the_key_packing_limit(gpu, oracle_mod, 16384, "matrix cores, index uses all 14 bits")
+    for first, stride in [(0, 2), (1, 2), (0, 3), (2, 1)]:
+        t2.test_match_pairs_strided(gpu, oracle_mod, 1, -1, 256, first, stride)
+
+
+def test_tile_matcher_is_what_a_large_call_runs(gpu, oracle_mod):
+    """600 frames x 500 keypoints: 599 (pair, tile) items >= 256, so the size rule itself takes match_tile_kernel; sampled
+    pairs against the oracle, the whole call against the stream form (forced on a second context)."""
+    torch, orbfe = gpu
+    B, n = 600, 500
+    rng = np.random.default_rng(77)
+    ctx = orbfe.Context(640, 480, cell=16, min_arc=9, max_features=n, max_batch=B)
+    assert ctx.cap == n and ctx.dispatch_info(B, 1, -1)["match"] == "match_tile_kernel"
+    pool = rng.integers(0, 256, (300, 32), dtype=np.uint8)  # a small pool: exact ties are frequent
+    rec = np.zeros((B, n), dtype=orbfe.KEYPOINT_DTYPE)
+    rec["desc"] = pool[rng.integers(0, 300, (B, n))]
+    flip = rng.random((B, n, 32)) < 0.02
+    rec["desc"] ^= (flip * rng.integers(1, 256, (B, n, 32))).astype(np.uint8)
+    rec["score"] = 20
+    cnt = rng.integers(0, n + 1, B).astype(np.int32)
+    cnt[:8] = [n, 0, n, 1, 17, 16, 15, n]
+    d_rec, d_cnt = dev(torch, rec.view(np.uint8).reshape(-1)), dev(torch, cnt)
+    out = {}
+    for form in ("auto", "stream"):
+        c = ctx
+        if form == "stream":
+            import os
+            os.environ["ORBFE_MATCH"] = "stream"
+            try:
+                c = orbfe.Context(640, 480, cell=16, min_arc=9, max_features=n, max_batch=B)
+            finally:
+                del os.environ["ORBFE_MATCH"]
+            assert c.dispatch_info(B, 1, -1)["match"] == "match_expand_kernel+match_mfma_kernel"
+        d_idx = torch.full(((B - 1) * n,), -7, dtype=torch.int32, device="cuda")
+        d_dst = torch.full(((B - 1) * n,), -7, dtype=torch.int32, device="cuda")
+        c.match_batch(d_rec.data_ptr(), d_cnt.data_ptr(), B, 1, -1, 100, d_idx.data_ptr(), d_dst.data_ptr(), stream(torch))
+        torch.cuda.synchronize()
+        out[form] = (d_idx.cpu().numpy().reshape(B - 1, n), d_dst.cpu().numpy().reshape(B - 1, n))
+    np.testing.assert_array_equal(out["auto"][0], out["stream"][0])
+    np.testing.assert_array_equal(out["auto"][1], out["stream"][1])
+    idx, dst = out["auto"]
+    for p in list(range(8)) + [100, 333, 598]:
+        A, Bf = rec[p, :cnt[p]], rec[p + 1, :cnt[p + 1]]
+        ref_idx, ref_dst = oracle_mod.match256(A["desc"], Bf["desc"], None, None, -1, 100)
+        np.testing.assert_array_equal(idx[p, :cnt[p]], ref_idx)
+        np.testing.assert_array_equal(dst[p, :cnt[p]], ref_dst)
+        assert (idx[p, cnt[p]:] == -1).all()
