@@ -578,11 +578,23 @@ def main():
                          "1024-frame gray figure as the key `ingest`")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the keypoint gather out of the timed region")
     ap.add_argument("--exact-gather", action="store_true", help="N > 1: variable-length gather (counts first, then exactly "
-                                                                  "sum(counts) * 52 bytes per rank)")
+                                                                  "sum(counts) * 52 bytes per rank); = --gather exact")
+    ap.add_argument("--gather", choices=("auto", "fixed", "exact"), default="auto",
+                    help="N > 1: which form of the keypoint gather.  fixed: cap records per frame whatever the counts, nothing touches "
+                         "the host; exact: counts first, then only the valid records (one host read of the counts per step); auto "
+                         "(default): exact when the frames fill less than three quarters of their record capacity (decided from one "
+                         "untimed extraction, the same on every rank), fixed otherwise")
+    ap.add_argument("--gather-every", type=int, default=1,
+                    help="N > 1: ship the records of every k-th step only (a consumer that samples the stream: the link carries 1 / k "
+                         "of the bytes).  1 = every step, what the BASELINE metric means; reported in the line when not 1")
     ap.add_argument("--dry-run", action="store_true", help="with --gpus N: print the child command lines and exit")
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
+    if args.gather_every < 1:
+        ap.error("--gather-every must be >= 1")
+    if args.exact_gather:
+        args.gather = "exact"
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # this process has not imported torch or touched HIP: start the ranks as children
@@ -720,6 +732,29 @@ def main():
 
     ctx = orbfe.Context(w, h, max_batch=max(B, 1), device=local_rank, **m["cfg"]) if B > 0 else None
     cap = ctx.cap if ctx else 0
+    base, frames = build_input(args.scene)
+    # --gather auto: one untimed extraction tells how full the records are; every rank must take the same form, so the
+    # decision is made on the global mean
+    gather_fill = None
+    if multi and args.mode != "c5" and args.gather == "auto":
+        kp_frames = torch.zeros(2, dtype=torch.float64, device=dev)
+        if B > 0:
+            r0 = torch.zeros(B * cap * 52, dtype=torch.uint8, device=dev)
+            c0 = torch.zeros(B, dtype=torch.int32, device=dev)
+            if args.rgb:
+                ctx.extract_rgb(frames.data_ptr(), 3 * w, 3 * w * h, B, r0.data_ptr(), c0.data_ptr(), None, s)
+            else:
+                ctx.extract(frames.data_ptr(), w, w * h, B, r0.data_ptr(), c0.data_ptr(), None, s)
+            torch.cuda.synchronize()
+            kp_frames[0], kp_frames[1] = float(c0.sum().item()), float(B)
+            del r0, c0
+        t = kp_frames.cpu() if share else kp_frames
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        gather_fill = float(t[0].item()) / max(float(t[1].item()) * max(cap, 1), 1.0)
+        args.exact_gather = gather_fill < 0.75
+    elif args.gather == "fixed":
+        args.exact_gather = False
     n_pairs = max((B - 2) // m["stride"] + 1, 0) if (mm and B >= 2) else 0
     # records / counts are double-buffered: the gather of step i overlaps the kernels of step i + 1
     recs = [torch.zeros(max(B, 1) * max(cap, 1) * 52, dtype=torch.uint8, device=dev) for _ in range(2)]
@@ -743,6 +778,7 @@ def main():
         b = state["step"] & 1
         frames = state["frames"][state["step"] % len(state["frames"])]  # --rotate: another resident batch every step
         state["step"] += 1
+        do_gather = do_gather and (state["step"] - 1) % args.gather_every == 0  # --gather-every k: steps 0, k, 2k, ...
         if do_gather:  # the gather that last read this buffer pair must be done before it is rewritten
             if comm is not None:
                 comm.wait_ticket(state["tickets"][b], s)
@@ -842,7 +878,6 @@ def main():
                     pairs_total=pairs_total, frames_total=frames_total, events=state["events"], steps=steps)
 
     use_gather = gather_ok and not args.no_gather
-    base, frames = build_input(args.scene)
     if args.rotate > 1:
         frames = [frames] + [build_input(args.scene, v)[1] for v in range(1, args.rotate)]
     # clock settling: ~50 ms of load before the warm-up steps (0.522 ms per 256-frame step after 3 warm-up steps,
@@ -851,9 +886,9 @@ def main():
     main_run = timed(frames, use_gather, True)
     extras = {}
     if not args.no_extras:
-        # the same step sustained for about a second (no stage events): the K-step figure above is not a
-        # burst, and whoever watches the GPU from outside sees it busy
-        n_long = max(args.steps, min(20000, int(1.0 / max(main_run["elapsed"] / args.steps, 1e-6))))
+        # the same step sustained for about three seconds (no stage events): the K-step figure above is not a
+        # burst, and whoever samples the GPU from outside every few seconds sees it busy
+        n_long = max(args.steps, min(60000, int(3.0 / max(main_run["elapsed"] / args.steps, 1e-6))))
         r1 = timed(frames, use_gather, False, steps=n_long)
         extras["sustained"] = {"steps": n_long, "value": r1["kp_total"] * n_long / r1["elapsed"], "unit": "keypoints/s",
                                "ms_per_step": r1["elapsed"] / n_long * 1e3, "seconds": r1["elapsed"]}
@@ -981,20 +1016,32 @@ def main():
         # the matrix cores for the brute-force matcher) sits beside it as named sub-objects, never in `frac`.
         # `limiter` is read from the counters of THIS build, not assumed from the stage's name: the largest of
         #   hbm  = PMC traffic / launch time / 6.29 TB/s (what a plain copy reaches on this chip),
-        #   valu = vector-instruction issue quad-cycles per SIMD-cycle (capped at 1),
+        #   valu = vector-instruction issue quad-cycles per SIMD-cycle / its ceiling 1.45,
         #   mfma = matrix-core flop fraction of the dense FP4 peak;  null when there are no PMC passes for this build
+        # VALU issue: the counter charges every vector instruction one quad-cycle (4 cycles) whatever it costs; a stream of
+        # full-rate instructions retires one per 2.76 cycles on this chip (tools/valu_rate5.hip), so the counter's CEILING is
+        # 4 / 2.76 = 1.45 per SIMD-cycle (0.96 for a stream of 4.15-cycle instructions): the utilisation is the raw value over
+        # that ceiling, both are printed, and a limiter is named only when it leads the runner-up by more than the
+        # calibration error (0.1) -- otherwise "a~b" 
+        VALU_ISSUE_CEILING = 4.0 / 2.76
+
         def limiter_of(e):
             util = {}
             if e.get("traffic"):
                 util["hbm"] = e["traffic"] / (e["ms"] * 1e-3) / 1e9 / 6290.0
             v = (e.get("valu") or {}).get("issue_quad_cycles_per_simd_cycle")
             if v is not None:
-                util["valu"] = min(v, 1.0)
+                util["valu"] = v / VALU_ISSUE_CEILING
+                e["valu"]["issue_ceiling"] = VALU_ISSUE_CEILING
+                e["valu"]["issue_utilisation"] = v / VALU_ISSUE_CEILING
             if e.get("mfma"):
                 util["mfma"] = e["mfma"]["frac"]
             if "hbm" not in util or "valu" not in util:
                 return None, util
-            return max(util, key=util.get), util
+            order = sorted(util, key=util.get, reverse=True)
+            if len(order) > 1 and util[order[0]] - util[order[1]] <= 0.1:
+                return order[0] + "~" + order[1], util
+            return order[0], util
         for e in per_stage.values():
             e["limiter"], e["limiter_utilisation"] = limiter_of(e)
         limiter = per_stage[dom]["limiter"]
@@ -1033,7 +1080,9 @@ def main():
                                        "records + counts to rank 0 inside the timed region, overlapped with the next step"
                                        % ("exact length" if args.exact_gather else "fixed stride")) if use_gather and comm
                                       else "torch.distributed gather (%s)" % ("gloo, shared-GPU rehearsal" if share else "nccl = RCCL") if use_gather
-                                      else "RCCL all-reduce(MAX) of the per-cell keys (liborbfe_dist.so)" if (args.mode == "c5" and multi)
+                                      else ("RCCL all-reduce(MAX) of the per-cell keys (liborbfe_dist.so)" if comm is not None else
+                                            "torch.distributed all-reduce(MAX) of the per-cell keys (%s)" % ("gloo, shared-GPU rehearsal" if share else "nccl = RCCL"))
+                                      if (args.mode == "c5" and multi)
                                       else "none in the data path; barrier + timing reductions only")},
             "frames_per_s": R["frames_total"] * args.steps / elapsed,
             # descriptor pairs compared per second: only where the matcher really examines every pair (the cell-indexed
@@ -1066,6 +1115,34 @@ def main():
                              "note": "fixed stride ships cap records per frame whatever the counts; the root's own block is written "
                                      "in place (no copy).  Hardware status: the world > 1 branch of liborbfe_dist.so has not run on "
                                      "a multi-GPU node of the build pool (world = 1 and gloo rehearsals only)" }
+        if not multi and m["scaling"] == "weak" and B > 0:
+            # What the link arithmetic predicts for the driver's N = 2, 4, 8 runs of this mode, so that the first run on a
+            # multi-GPU node is a check, not a discovery.  Model: the gather of step i rides under the
+            # kernels of step i + 1 (double-buffered records), every non-root rank ships its block over ITS OWN xGMI link to
+            # the root (76.8 GB/s one way; <= 7 peers, so the root's links never share), hence a steady-state step takes
+            # max(compute, bytes per rank / link rate) whatever N is, and weak-scaling efficiency = compute / that.  Two link
+            # rates: the 76.8 GB/s peak and 0.8 of it (what a send / recv pair is assumed to sustain; unmeasured here).
+            fixed_b = B * cap * 52 + 4 * B
+            exact_b = int(R["kp_local"]) * 52 + 4 * B
+            fill = R["kp_local"] / max(B * cap, 1)
+            auto_form = "exact" if fill < 0.75 else "fixed"
+
+            def predict(nbytes):
+                o = {"bytes_per_nonroot_rank_per_step": nbytes}
+                for tag, rate in (("at_link_peak", 76.8e9), ("at_0.8_of_link_peak", 0.8 * 76.8e9)):
+                    t_link = nbytes / rate * 1e3
+                    o[tag] = {"link_ms_per_step": t_link, "step_ms": max(ms_step, t_link),
+                              "weak_scaling_efficiency": ms_step / max(ms_step, t_link), "bound": "link" if t_link > ms_step else "compute"}
+                return o
+            out["scaling_prediction"] = {
+                "n_gpus": [2, 4, 8], "compute_ms_per_step": ms_step, "record_fill": fill, "auto_form": auto_form,
+                "fixed_stride": predict(fixed_b), "exact_length": predict(exact_b),
+                "gather_every_2_fixed_stride": predict(fixed_b / 2.0),
+                "note": "same prediction for N = 2, 4 and 8 (point-to-point links: every peer has its own to the root); the exact form "
+                        "adds one host read of the counts per step, not modelled; --gather auto picks `auto_form`"}
+        if multi:
+            out.setdefault("gather", {})["every"] = args.gather_every
+            out["gather"]["record_fill_probe"] = gather_fill
         out.update(extras)
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(base, args.mode)
