@@ -420,7 +420,7 @@ def align_bench(args, torch, np, orbfe, dev, json_out):
     json_out.flush()
 
 
-def ingest_bench(torch, np, orbfe, synth, dev, mode, scene, frames_per_slot, passes=12, slots=3, rgb=False, pageable=False):
+def ingest_bench(torch, np, orbfe, synth, dev, mode, scene, frames_per_slot, passes=36, slots=3, rgb=False, pageable=False):
     """SURVEY.md 8f-1, the staging half (include/orbfe_ingest.h; buildStream.cpp:376-381, :399-406, :462-466, :483-487):
     the SAME step as the headline (orbfe_extract + orbfe_match_batch), but the frames start in pinned HOST memory and the
     records, counts and matcher outputs end there.  Three figures per slot of `frames_per_slot` frames:
@@ -545,6 +545,8 @@ def ingest_bench(torch, np, orbfe, synth, dev, mode, scene, frames_per_slot, pas
                          "peak_measured_pinned": peak_h2d, "frac_of_peak": up_bytes / t_pipe / 1e9 / peak_h2d},
             "d2h_GBps": {"achieved_pipelined": down_bytes / t_pipe / 1e9, "peak_measured_pinned": peak_d2h},
             "bidirectional_GBps_measured_pinned": 2 * big / t_bidir / 1e9,
+            # (the timed region includes the ring's fill and drain: one upload + compute + download of a slot that overlaps nothing,
+            # i.e. about (compute + download) / passes per slot on top of the steady state)
             "overlap_efficiency": bound / t_pipe, "bound_by": "pcie_h2d" if t_copy >= t_compute else "compute",
             "copy_over_compute": t_copy / t_compute,
             "note": "same step as `value` of the headline but host -> device -> host; overlap_efficiency = max(copy alone, compute "
@@ -685,7 +687,7 @@ def main():
         for F, rgb, pageable in ((256, False, False), (1024, False, False), (4096, False, False), (1024, True, False),
                                  (1024, False, True)):
             F = min(F, args.batch) if args.batch else F
-            runs.append(ingest_bench(torch, np, orbfe, synth, dev, mode, args.scene, F, passes=max(args.steps, 12) if F < 4096 else 9,
+            runs.append(ingest_bench(torch, np, orbfe, synth, dev, mode, args.scene, F, passes=max(args.steps, 36) if F < 4096 else 18,
                                      rgb=rgb, pageable=pageable))
         head = next(r for r in runs if r["frames_per_slot"] == (min(1024, args.batch) if args.batch else 1024) and r["input"] == "gray"
                     and r["source"].startswith("pinned"))
@@ -907,7 +909,7 @@ def main():
         if world == 1 and args.mode in ("c2", "ref") and not args.rgb:
             # f1's staging half: the same step with the frames starting in pinned host memory and the results ending there
             try:
-                extras["ingest"] = ingest_bench(torch, np, orbfe, synth, dev, args.mode, args.scene, min(1024, max(B, 2)), passes=12)
+                extras["ingest"] = ingest_bench(torch, np, orbfe, synth, dev, args.mode, args.scene, min(1024, max(B, 2)), passes=36)
             except Exception as e:  # never lose the headline over the extra
                 extras["ingest"] = {"error": str(e)}
         if args.mode == "c2" and world == 1:
@@ -1103,7 +1105,7 @@ def main():
         if multi:
             # what the gather moves, so that the first real multi-GPU run explains itself: xGMI is point to point, every
             # non-root rank ships its block over its own link to the root (7 links x ~153 GB/s peak per GPU)
-            rec_bytes = (int(R["counts"].sum()) if args.exact_gather else B * cap) * 52 + 4 * B
+            rec_bytes = ((int(R["counts"].sum()) if args.exact_gather else B * cap) * 52 + 4 * B) / float(args.gather_every)
             out["gather"] = {"form": "exact" if args.exact_gather else "fixed_stride",
                              "bytes_shipped_per_nonroot_rank_per_step": rec_bytes if use_gather else 0,
                              "root_ingress_bytes_per_step": rec_bytes * (world - 1) if use_gather else 0,
@@ -1113,8 +1115,9 @@ def main():
                              "xgmi_link_peak_GBps_one_way": 76.8, "xgmi_link_peak_GBps_bidirectional": 153.6, "links_per_gpu": 7,
                              "link_utilisation_one_way": ((rec_bytes / (ms_step * 1e-3) / 1e9) / 76.8) if use_gather else 0.0,
                              "note": "fixed stride ships cap records per frame whatever the counts; the root's own block is written "
-                                     "in place (no copy).  Hardware status: the world > 1 branch of liborbfe_dist.so has not run on "
-                                     "a multi-GPU node of the build pool (world = 1 and gloo rehearsals only)" }
+                                     "in place (no copy); with --gather-every k the bytes are the per-step average.  Hardware status: the world > 1 "
+                                     "branch of liborbfe_dist.so runs in the GPU tests over a loopback stand-in for librccl (2 and 3 ranks on "
+                                     "one device, tests/fake_rccl); the xGMI transport itself has not run on a multi-GPU node of the build pool"}
         if not multi and m["scaling"] == "weak" and B > 0:
             # What the link arithmetic predicts for the driver's N = 2, 4, 8 runs of this mode, so that the first run on a
             # multi-GPU node is a check, not a discovery.  Model: the gather of step i rides under the
