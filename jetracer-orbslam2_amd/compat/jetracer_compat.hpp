@@ -135,29 +135,32 @@ inline void match_keypoints(const float2 *d_pos_prev_reprojected, const uint32_t
                                         detail::S(stream)), "match_keypoints");
 }
 
-// src/cuda/cuda-align.cuh:37-46 (rs2_intrinsics / rs2_extrinsics -> the layout-identical orbfe structs, on the
-// HOST: the reference uploads device copies once, SlamGpuPipeline.cpp:53-86; here they travel as kernel arguments).
-// d_pixel_map is accepted and ignored (the fused kernel has no map).
+// src/cuda/cuda-align.cuh:37-46 (rs2_intrinsics / rs2_extrinsics -> the layout-identical orbfe structs).  The three
+// camera structs may be the reference's DEVICE copies (_d_depth_intrinsics, _d_rgb_intrinsics, _d_depth_rgb_extrinsics:
+// SlamGpuPipeline.cpp:53-55, passed at buildStream.cpp:391-393 -- a port keeps those arguments as they are: the library
+// detects device memory and copies the 48 bytes back once per call) or plain host structs; either way the values reach
+// the kernels as launch arguments.  d_pixel_map is accepted and ignored (the fused kernel has no map).
 inline void align_depth_to_other(unsigned int *d_aligned_out, const uint16_t *d_depth_in, int2 *d_pixel_map,
                                  float depth_scale, int image_width, int image_height,
-                                 const orbfe_intrinsics *h_depth_intrin, const orbfe_intrinsics *h_other_intrin,
-                                 const orbfe_extrinsics *h_depth_to_other, hipStream_t stream)
+                                 const orbfe_intrinsics *depth_intrin, const orbfe_intrinsics *other_intrin,
+                                 const orbfe_extrinsics *depth_to_other, hipStream_t stream)
 {
     detail::check(orbfe_align_depth_to_other(d_aligned_out, d_depth_in, d_pixel_map, depth_scale, image_width,
-                                             image_height, h_depth_intrin, h_other_intrin, h_depth_to_other,
+                                             image_height, depth_intrin, other_intrin, depth_to_other,
                                              detail::S(stream)), "align_depth_to_other");
 }
 
 // src/cuda/cuda-align.cuh:48-61 (host :401-443): like the reference it zeroes the counter, launches, and queues the
 // copy of the count to *h_valid_keypoints_num on `stream` (valid after the caller's next synchronisation, as in
 // buildStream.cpp:468-487).  fix_depth_index = 0: the reference's depth[int(y+.5) * W + int(y+.5)] lookup (:332).
-inline void keypoint_pixel_to_point(unsigned int *d_aligned_depth, const orbfe_intrinsics *h_rgb_intrin, int image_width,
+// (rgb_intrin: host or device pointer, as above)
+inline void keypoint_pixel_to_point(unsigned int *d_aligned_depth, const orbfe_intrinsics *rgb_intrin, int image_width,
                                     int image_height, float2 *d_pos_out, float2 *d_pos_in, float *d_score,
                                     double *d_points, uint32_t *d_descriptors_out, uint32_t *d_descriptors_in,
                                     int keypoints_num, int *h_valid_keypoints_num, int *d_valid_keypoints_num,
                                     hipStream_t stream)
 {
-    detail::check(orbfe_keypoint_pixel_to_point(d_aligned_depth, h_rgb_intrin, image_width, image_height,
+    detail::check(orbfe_keypoint_pixel_to_point(d_aligned_depth, rgb_intrin, image_width, image_height,
                                                 reinterpret_cast<float *>(d_pos_out),
                                                 reinterpret_cast<const float *>(d_pos_in), d_score, d_points,
                                                 d_descriptors_out, d_descriptors_in, keypoints_num,

@@ -28,7 +28,7 @@ def gpu():
     assert torch.cuda.is_available(), "GPU tests need a HIP device"
     built = [orbfe.LIB_PATH, os.path.join(ROOT, "jetracer-orbslam2_amd", "liborbfe_dist.so"),
              os.path.join(ROOT, "examples", "buildstream_port"), os.path.join(ROOT, "examples", "match_port"),
-             os.path.join(ROOT, "examples", "multi_gpu_port")]
+             os.path.join(ROOT, "examples", "multi_gpu_port"), os.path.join(ROOT, "examples", "ingest_port")]
     if not all(os.path.exists(b) for b in built):
         import __graft_entry__  # clean checkout: build the HIP library, the oracle and the example
         __graft_entry__.build()

@@ -165,6 +165,43 @@ def test_ingest_pageable_source_with_a_pitch_and_device_side_consumer(gpu, oracl
     ctx.close()
 
 
+@pytest.mark.parametrize("rgb", [False, True])
+def test_cpp_ingest_port(gpu, oracle_mod, tmp_path, rgb):
+    """examples/ingest_port.cpp: the host side of the reference's frame loop (pageable camera frames in, host results out;
+    buildStream.cpp:376-381, :399-406, :462-466, :483-487) as a C++ program over include/orbfe_ingest.h only -- 11 frames in
+    batches of 3 through 3 pinned slots (a partial last batch, every slot reused).  Its output file must hold the oracle's
+    records frame by frame and the brute-force matches of consecutive frames inside a batch."""
+    torch, orbfe = gpu
+    exe = os.path.join(ROOT, "examples", "ingest_port")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    w, h, n, per = 640, 480, 11, 3
+    g = np.stack([synth.frame(w, h, 400 + i, "rects", n_rects=96 if i % 3 else 800, min_size=6, max_size=None if i % 3 else 32) for i in range(n)])
+    frames = np.stack([g, np.roll(g, 2, 2), 255 - g], -1) if rgb else g
+    fin, fout = str(tmp_path / "frames.bin"), str(tmp_path / "out.bin")
+    np.ascontiguousarray(frames).tofile(fin)
+    r = subprocess.run([exe, str(w), str(h), str(n), str(per), fin, fout] + (["rgb"] if rgb else []), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=240)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")
+    assert b"4 batches" in r.stdout and b"3 pinned slots" in r.stdout
+    raw = np.fromfile(fout, np.uint8)
+    nf, cap = raw[:8].view(np.int32)
+    assert nf == n and cap == 2000
+    counts = raw[8:8 + 4 * n].view(np.int32)
+    o = 8 + 4 * n
+    rec = raw[o:o + n * cap * 52].view(orbfe.KEYPOINT_DTYPE).reshape(n, cap)
+    idx = raw[o + n * cap * 52:].view(np.int32).reshape(n, cap)
+    ocfg = oracle_mod.make_config(w, h, levels=8, cell=8, min_arc=9, max_features=2000)
+    refs = [oracle_mod.extract_frame(oracle_mod.rgb_to_grayscale(frames[f]) if rgb else frames[f], ocfg) for f in range(n)]
+    for f in range(n):
+        assert counts[f] == refs[f]["count"] > 100
+        assert rec[f, :counts[f]].tobytes() == refs[f]["records"].tobytes()
+        if f % per != per - 1 and f != n - 1:  # a pair inside a batch
+            want, _ = oracle_mod.match256(refs[f]["records"]["desc"], refs[f + 1]["records"]["desc"])
+            np.testing.assert_array_equal(idx[f, :counts[f]], want)
+        else:
+            assert (idx[f] == -1).all()
+
+
 def test_ingest_slot_state_machine(gpu):
     """A slot is free or in flight: a second submit without a wait is ORBFE_ERR_CAPACITY (the ring is full), a wait on a
     free slot and a timing query before any pass are ORBFE_ERR_INVALID_ARG, sizes beyond the slot or the context are
