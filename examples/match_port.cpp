@@ -50,8 +50,10 @@ struct Pipeline { // the per-stream buffers of buildStream.cpp:233-336
     float *d_score;
     int *d_level, *d_valid_keypoints_num;
     std::vector<pyramid_t> pyramid;
-    orbfe_intrinsics depth_intrin, rgb_intrin;
-    orbfe_extrinsics depth_rgb_extrinsics;
+    // the reference's DEVICE copies of the camera structs (SlamGpuPipeline.cpp:53-55 cudaMalloc, upload_intristics :58-86):
+    // passed on exactly as buildStream.cpp:391-393, :469 and post_processing.cuh:45 do
+    orbfe_intrinsics *_d_depth_intrinsics, *_d_rgb_intrinsics;
+    orbfe_extrinsics *_d_depth_rgb_extrinsics;
     float depth_scale;
     hipStream_t stream, align_stream;
 };
@@ -62,8 +64,8 @@ static std::shared_ptr<slam_frame_t> process(Pipeline &p, const std::vector<unsi
     // --------------- align depth to RGB (buildStream.cpp:376-394): its own stream, in parallel with the keypoints
     CHECK(hipMemcpyAsync(p.d_depth_in, h_depth.data(), h_depth.size() * sizeof(uint16_t), hipMemcpyHostToDevice,
                          p.align_stream));
-    align_depth_to_other(p.d_aligned_out, p.d_depth_in, p.d_pixel_map, p.depth_scale, p.cam_w, p.cam_h, &p.depth_intrin,
-                         &p.rgb_intrin, &p.depth_rgb_extrinsics, p.align_stream);
+    align_depth_to_other(p.d_aligned_out, p.d_depth_in, p.d_pixel_map, p.depth_scale, p.cam_w, p.cam_h, p._d_depth_intrinsics,
+                         p._d_rgb_intrinsics, p._d_depth_rgb_extrinsics, p.align_stream);
     CHECK(hipMemcpy2DAsync(p.d_rgb_image, p.rgb_pitch, h_rgb.data(), (size_t)p.cam_w * 3, (size_t)p.cam_w * 3, p.cam_h,
                            hipMemcpyHostToDevice, p.stream));
     rgb_to_grayscale(p.d_gray_image, p.d_rgb_image, p.cam_w, p.cam_h, (int)p.gray_pitch, (int)p.rgb_pitch, p.stream);
@@ -84,7 +86,7 @@ static std::shared_ptr<slam_frame_t> process(Pipeline &p, const std::vector<unsi
     // the reference reads d_aligned_out on `stream` and only synchronises align_stream afterwards (:468-487), a race
     // it gets away with; ordered here
     CHECK(hipStreamSynchronize(p.align_stream));
-    keypoint_pixel_to_point(p.d_aligned_out, &p.rgb_intrin, p.cam_w, p.cam_h, frame->d_pos, p.d_pos, p.d_score,
+    keypoint_pixel_to_point(p.d_aligned_out, p._d_rgb_intrinsics, p.cam_w, p.cam_h, frame->d_pos, p.d_pos, p.d_score,
                             frame->d_points, frame->d_descriptors, p.d_descriptors, (int)p.keypoints_num,
                             &frame->h_valid_keypoints_num, p.d_valid_keypoints_num, p.stream);
     CHECK(hipStreamSynchronize(p.stream));
@@ -115,9 +117,12 @@ int main(int argc, char **argv)
         float depth_scale;
     } rig;
     read_file(argv[6], &rig, sizeof(rig));
-    p.depth_intrin = rig.depth;
-    p.rgb_intrin = rig.rgb;
-    p.depth_rgb_extrinsics = rig.depth_to_rgb;
+    CHECK(hipMalloc((void **)&p._d_depth_intrinsics, sizeof(orbfe_intrinsics)));
+    CHECK(hipMalloc((void **)&p._d_rgb_intrinsics, sizeof(orbfe_intrinsics)));
+    CHECK(hipMalloc((void **)&p._d_depth_rgb_extrinsics, sizeof(orbfe_extrinsics)));
+    CHECK(hipMemcpy(p._d_depth_intrinsics, &rig.depth, sizeof(orbfe_intrinsics), hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(p._d_rgb_intrinsics, &rig.rgb, sizeof(orbfe_intrinsics), hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(p._d_depth_rgb_extrinsics, &rig.depth_to_rgb, sizeof(orbfe_extrinsics), hipMemcpyHostToDevice));
     p.depth_scale = rig.depth_scale;
 
     CHECK(hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
@@ -157,7 +162,7 @@ int main(int argc, char **argv)
     CHECK(hipMalloc((void **)&d_keypoints_num_matched, sizeof(int)));
     std::vector<double3> h_curr(p.keypoints_num), h_prev(p.keypoints_num);
     match_keypoints(slam_frame, previous_frame, 2, 4, T_w2c_prev_curr, p.d_valid_keypoints_num, d_keypoints_num_matched,
-                    &h_keypoints_num_matched, h_curr.data(), h_prev.data(), &p.rgb_intrin, p.stream);
+                    &h_keypoints_num_matched, h_curr.data(), h_prev.data(), p._d_rgb_intrinsics, p.stream);
 
     const int n = h_keypoints_num_matched;
     FILE *f = std::fopen(argv[7], "wb");

@@ -221,8 +221,8 @@ inline void hip_check(hipError_t e, const char *what)
 
 // src/cuda/post_processing.cuh:40-51 / post_processing.cu:234-341, argument for argument:
 //   Eigen::Matrix4d T_w2c_prev_curr  -> its 16 doubles (T.data());
-//   const rs2_intrinsics *d_rgb_intrin -> the same struct on the HOST (orbfe_intrinsics has rs2_intrinsics'
-//     layout; the library passes it to the kernel by value);
+//   const rs2_intrinsics *d_rgb_intrin -> the same pointer: orbfe_intrinsics has rs2_intrinsics' layout, and the
+//     library takes the reference's device copy (_d_rgb_intrinsics) or a host struct alike;
 //   d_valid_keypoints_num (a device int the reference's kernel dereferences) is unused: the count is
 //     current_frame->h_valid_keypoints_num.
 // Same observable results: h_*_matched_points, *h_keypoints_num_matched, current_frame->keypoints_x / _y
@@ -232,7 +232,7 @@ inline void match_keypoints(std::shared_ptr<slam_frame_t> current_frame, std::sh
                             int max_pixel_distance, int max_hamming_distance, const double *T_w2c_prev_curr,
                             int * /*d_valid_keypoints_num*/, int *d_keypoints_num_matched, int *h_keypoints_num_matched,
                             double3 *h_current_matched_points, double3 *h_previous_matched_points,
-                            const orbfe_intrinsics *h_rgb_intrin, hipStream_t stream)
+                            const orbfe_intrinsics *d_rgb_intrin, hipStream_t stream)
 {
     const int n_prev = previous_frame->h_valid_keypoints_num, n_curr = current_frame->h_valid_keypoints_num;
     const int cap = previous_frame->keypoints_count > n_prev ? previous_frame->keypoints_count : n_prev;
@@ -247,7 +247,7 @@ inline void match_keypoints(std::shared_ptr<slam_frame_t> current_frame, std::sh
     detail::hip_check(hipMalloc((void **)&d_prev_m, sizeof(double3) * n), "hipMalloc");
     detail::hip_check(hipMalloc((void **)&d_curr_m, sizeof(double3) * n), "hipMalloc");
     detail::check(orbfe_reproject_points(reinterpret_cast<float *>(d_pos_tmp), previous_frame->d_points, n_prev,
-                                         T_w2c_prev_curr, h_rgb_intrin, detail::S(stream)), "reproject_points");
+                                         T_w2c_prev_curr, d_rgb_intrin, detail::S(stream)), "reproject_points");
     detail::check(orbfe_match_keypoints(reinterpret_cast<const float *>(d_pos_tmp), previous_frame->d_descriptors, n_prev,
                                         reinterpret_cast<const float *>(current_frame->d_pos),
                                         current_frame->d_descriptors, n_curr, max_pixel_distance, max_hamming_distance,
