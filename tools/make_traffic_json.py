@@ -27,7 +27,7 @@ STAGES = {
     "describe": ["select_kernel", "describe_tile_kernel", "describe_kernel"],
     "align": ["align_fill_kernel", "align_splat_kernel", "align_unmax_kernel"],
     "match": ["match_gather_kernel", "match_batch_256_kernel", "match_batch_ref_kernel", "match_expand_kernel",
-              "match_mfma_kernel", "match_bucket_kernel", "match_window_kernel"],
+              "match_mfma_kernel", "match_tile_kernel", "match_bucket_kernel", "match_window_kernel"],
 }
 
 

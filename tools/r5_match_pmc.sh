@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 5: matrix-pipe / vector-ALU counters of the matcher forms (product, ORBFE_MATCH_V2 variants) on the default bench step
+# round 5: matrix-pipe / vector-ALU counters of the matcher on the default bench step: the product (base; ORBFE_MATCH=stream | tile in
+# the environment forces a form) and, with a build of tools/experiments/matcher_forms.patch selected by ORBFE_LIB, its ORBFE_MATCH_V2 variants
 # usage (through gpurun): tools/r5_match_pmc.sh <tag> [variants...]   -> gpurun_out/<tag>/pmc_<variant>.json + a table
 TAG=${1:-r5pmc}; shift
 VARS=${@:-base 22 t2}
@@ -27,7 +28,7 @@ for v in "$VARS".split():
     except Exception:
         pass
     for k, c in d.items():
-        if "match_mfma" not in k: continue
+        if "match_mfma" not in k and "match_tile" not in k: continue
         g = lambda n: c.get(n, {}).get("avg", 0)
         cyc = g("GRBM_GUI_ACTIVE") / 8
         simd = 1024 * max(cyc, 1)
