@@ -16,6 +16,8 @@ from orbfe import synth  # noqa: E402
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 CASES = [
     ("c2", 640, 480, 32, dict(levels=8, cell=8, min_arc=9, max_features=2000), dict(mode=1, window=-1, md=64, stride=1)),
+    # 71 pairs x 4 query tiles >= 256 work items: the size rule takes match_tile_kernel (LDS ring, one barrier per step)
+    ("c2_tile", 640, 480, 72, dict(levels=8, cell=8, min_arc=9, max_features=2000), dict(mode=1, window=-1, md=64, stride=1)),
     ("c3", 848, 480, 32, dict(levels=8, cell=8, min_arc=9, max_features=2000), dict(mode=1, window=16, md=80, stride=2)),
     ("ref", 640, 480, 32, dict(), dict(mode=0, window=32, md=8, stride=1)),
     ("c5", 3840, 2160, 2, dict(levels=12, cell=16, min_arc=9, max_features=8000), dict(mode=1, window=-1, md=64, stride=1)),
