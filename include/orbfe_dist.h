@@ -19,9 +19,11 @@
  *
  * There is NO CPU fallback: without a HIP device / RCCL every call returns an error status.
  *
- * VERIFICATION STATUS: with one rank (world = 1) every entry point is exercised on hardware by the GPU
- * tests; the code under `world > 1` (grouped ncclSend / ncclRecv, the all-reduce) has NOT executed on any
- * multi-GPU node available to the build -- see DESIGN.md section 5.
+ * VERIFICATION STATUS: with one rank (world = 1) every entry point is exercised on hardware by the GPU tests.  The code
+ * under `world > 1` (grouped ncclSend / ncclRecv, root placement, exact-length packing, the all-reduce) runs in the GPU
+ * tests with 2 and 3 ranks on ONE device over a test-only loopback stand-in for librccl.so.1 (tests/fake_rccl: real RCCL
+ * refuses two ranks on one GPU), against the oracle.  What has not executed on any multi-GPU node available to the build
+ * is RCCL's own xGMI transport -- see DESIGN.md section 5.
  */
 #ifndef ORBFE_DIST_H
 #define ORBFE_DIST_H

@@ -578,3 +578,40 @@ def test_tile_matcher_is_what_a_large_call_runs(gpu, oracle_mod):
         np.testing.assert_array_equal(idx[p, :cnt[p]], ref_idx)
         np.testing.assert_array_equal(dst[p, :cnt[p]], ref_dst)
         assert (idx[p, cnt[p]:] == -1).all()
+
+
+def test_tile_matcher_fuzz(gpu, oracle_mod, monkeypatch):
+    """Random record capacities (not multiples of 16 or 512, 1 .. ~5000), random counts (0, 1, 15, 16, 17, cap), a small
+    descriptor pool (exact ties: the lower index must win), random distance limits -- match_tile_kernel forced, against the
+    oracle.  ORBFE_FUZZ_TRIALS / ORBFE_FUZZ_SEED as in the other fuzzes."""
+    torch, orbfe = gpu
+    monkeypatch.setenv("ORBFE_MATCH", "tile")
+    trials = int(os.environ.get("ORBFE_FUZZ_TRIALS", "10"))
+    rng = np.random.default_rng(int(os.environ.get("ORBFE_FUZZ_SEED", "505")))
+    for trial in range(trials):
+        cell = int(rng.choice([8, 16, 32]))
+        w, h = int(rng.integers(5, 40)) * cell + int(rng.integers(0, cell)), int(rng.integers(4, 30)) * cell + int(rng.integers(0, cell))
+        K = ((w + cell - 1) // cell) * ((h + cell - 1) // cell)
+        maxf = int(rng.choice([0, 0, max(1, K // 3), max(1, K - 1)]))
+        n = int(rng.integers(2, 6))
+        ctx = orbfe.Context(w, h, cell=cell, min_arc=9, max_features=maxf, max_batch=n)
+        cap = ctx.cap
+        assert ctx.dispatch_info(n, 1, -1)["match"] == "match_tile_kernel"
+        pool = rng.integers(0, 256, (max(4, cap // 5), 32), dtype=np.uint8)
+        pool[0], pool[1] = 0, 255
+        rec = np.zeros((n, cap), dtype=orbfe.KEYPOINT_DTYPE)
+        rec["desc"] = pool[rng.integers(0, len(pool), (n, cap))]
+        rec["desc"] ^= ((rng.random((n, cap, 32)) < 0.03) * rng.integers(1, 256, (n, cap, 32))).astype(np.uint8)
+        cnt = np.array([int(rng.choice([0, 1, min(15, cap), min(16, cap), min(17, cap), cap, int(rng.integers(0, cap + 1))])) for _ in range(n)], np.int32)
+        maxd = int(rng.choice([256, 0, 40, 128]))
+        d_rec, d_cnt = dev(torch, rec.view(np.uint8).reshape(-1)), dev(torch, cnt)
+        d_idx = torch.full(((n - 1) * cap,), -7, dtype=torch.int32, device="cuda")
+        d_dst = torch.full(((n - 1) * cap,), -7, dtype=torch.int32, device="cuda")
+        ctx.match_batch(d_rec.data_ptr(), d_cnt.data_ptr(), n, 1, -1, maxd, d_idx.data_ptr(), d_dst.data_ptr(), stream(torch))
+        idx, dst = d_idx.cpu().numpy().reshape(n - 1, cap), d_dst.cpu().numpy().reshape(n - 1, cap)
+        for p in range(n - 1):
+            ri, rd = oracle_mod.match256(rec[p, :cnt[p]]["desc"], rec[p + 1, :cnt[p + 1]]["desc"], None, None, -1, maxd)
+            np.testing.assert_array_equal(idx[p, :cnt[p]], ri, err_msg="trial %d pair %d cap %d counts %s" % (trial, p, cap, cnt))
+            np.testing.assert_array_equal(dst[p, :cnt[p]], rd)
+            assert (idx[p, cnt[p]:] == -1).all() and (dst[p, cnt[p]:] == -1).all()
+        ctx.close()
