@@ -270,7 +270,7 @@ match_mfma_kernel(const uint4 *__restrict__ mexp, const float *__restrict__ mkey
 //     e2m1 scratch (128 B + a key per keypoint, written once and read as the A and as the B operand: the stage moved 5.2 x
 //     its algorithmic bytes, and the kernel was 0.29 ms of every step) is not used.  Wave w takes block w of a step --
 //     two dwords of descriptor per lane (lane L: words L >> 4 and (L >> 4) + 4 of keypoint L & 15, exactly the fragment
-//     entries [k-step 0 / 1][lane L]), eight 8-bit -> 8-nibble spreads riding in the MFMA gaps next to the folds, the
+//     entries [k-step 0 / 1][lane L]), eight dwords of e2m1 nibbles made by ten ANDs / shifts in the MFMA gaps next to the folds, the
 //     popcount for the column key met by two lane shuffles -- and writes fragment image and key tuples into the ring with
 //     ds_write_b128.  The queries are expanded the same way in the prologue.  No LDS-DMA, no scratch: 32 bytes of HBM
 //     traffic per keypoint and workgroup instead of 128 + 128 per keypoint and call plus the scratch's own round trip.
@@ -283,9 +283,42 @@ match_mfma_kernel(const uint4 *__restrict__ mexp, const float *__restrict__ mkey
 // every form).  Measured: match stage 1.654 -> 1.522 ms per 4096 frames, step 5.99 -> 5.79 ms.
 constexpr int kTileBlk = 2048 + 256; // one candidate block in the ring: fragment image + 16 keys x 4 copies
 constexpr int kTileSlot = 4 * kTileBlk;
-__device__ __forceinline__ u32x4 spread_word_e2m1(uint32_t w)
+// The tile kernel's own order of the 256 bits inside K (any order serves as long as queries and candidates share it): dword d of
+// a lane's fragment entry holds bits d, d + 4, ..., d + 28 of its descriptor word, one per nibble, so the CANDIDATE side of the
+// expansion -- the one inside the loop -- is a plain AND per dword.  The e2m1 code a set bit carries is whatever the AND leaves
+// (0x1 = 0.5, 0x2 = 1.0, 0x4 = 2.0; bit 3 of a nibble is the sign, so dword 3 is shifted down by one); the QUERY side, expanded
+// once per kernel, carries the reciprocal, and every product of two set bits is exactly 1:
+//     dword          0                    1                    2                    3
+//     candidate      w & 0x11111111 (0.5) w & 0x22222222 (1.0) w & 0x44444444 (2.0) (w >> 1) & 0x44444444 (2.0)
+//     query          2.0                  1.0                  0.5                  0.5
+// Ten full-rate instructions per two descriptor words, where the bytewise spread above (bit b -> nibble b, the order the scratch
+// of the other forms is defined in) compiles to 2 v_mul_u32_u24_sdwa + v_bitop3 + a quarter-rate v_mul_lo_u32 + v_and for each
+// of the eight bytes (0.19 ms of the kernel's 1.59 per 4096-frame step, profiles/r05_tile_ablation.txt).
+template <int D> __device__ __forceinline__ uint32_t tile_cand_dword(uint32_t w)
 {
-    return (u32x4){spread_bits_e2m1(w), spread_bits_e2m1(w >> 8), spread_bits_e2m1(w >> 16), spread_bits_e2m1(w >> 24)};
+    return D == 0 ? w & 0x11111111u : D == 1 ? w & 0x22222222u : D == 2 ? w & 0x44444444u : (w >> 1) & 0x44444444u;
+}
+__device__ __forceinline__ u32x4 tile_cand_word(uint32_t w)
+{
+    return (u32x4){tile_cand_dword<0>(w), tile_cand_dword<1>(w), tile_cand_dword<2>(w), tile_cand_dword<3>(w)};
+}
+// x summed over lanes L and L ^ 16 (L ^ 32): gfx950's row swaps are vector instructions -- v0.row1 <-> v1.row0, v0.row3 <-> v1.row2
+// (v0.rows 2, 3 <-> v1.rows 0, 1), so with both operands = x the two results are the two rows' (halves') values in every lane
+__device__ __forceinline__ int sum_lanes_xor16(int x)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);
+    return (int)(r[0] + r[1]);
+}
+__device__ __forceinline__ int sum_lanes_xor32(int x)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+    return (int)(r[0] + r[1]);
+}
+// colkey of candidate kp with |b| = pc (see (2) above); past the count (kp < 0): never wins
+__device__ __forceinline__ float column_key(int pc, int kp) { return kp >= 0 ? -(float)(pc * kMmaS + kp) * kKeyUnit : -1e30f; }
+__device__ __forceinline__ u32x4 tile_query_word(uint32_t w)
+{
+    return (u32x4){(w & 0x11111111u) << 2, w & 0x22222222u, (w & 0x44444444u) >> 2, (w >> 3) & 0x11111111u};
 }
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 match_tile_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *__restrict__ counts, int cap, int first,
@@ -338,6 +371,7 @@ match_tile_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *__r
     // the expansion of a source, in pieces a row block's scheduling region can take one at a time
     struct Exp {
         u32x4 f0, f1;
+        int pc; // |b| on its way: this lane's two words, then the keypoint's eight
         float key;
     };
     // fragment image + key tuples of this wave's block into slot `s` (all LDS traffic of the loop is hand-written: the
@@ -357,7 +391,7 @@ match_tile_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *__r
         u32x4 q0, q1, r0, r1;
         v4f cv, dv;
     };
-    auto read2 = [](auto off_c, Ops &o, uint32_t lds16, uint32_t ldsk) {
+    auto read2 = [](auto off_c, Ops &o, uint32_t lds16, uint32_t ldsk) { // (the prologue's; the loop spreads its reads, see mma2)
         constexpr int off = decltype(off_c)::value;
         asm volatile("ds_read_b128 %0, %6 offset:%8\n\tds_read_b128 %1, %6 offset:%9\n\t"
                      "ds_read_b128 %2, %7 offset:%10\n\t"
@@ -371,18 +405,27 @@ match_tile_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *__r
     auto landed = [](Ops &o) { // the wait is tied to the registers, so nothing reads (or copies) them before it
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o.q0), "+v"(o.q1), "+v"(o.cv), "+v"(o.r0), "+v"(o.r1), "+v"(o.dv)::"memory");
     };
+    const uint32_t wr16 = lds16 + (uint32_t)wv * kTileBlk, wrk = ldsk + (uint32_t)wv * kTileBlk; // this wave's block of a slot
     const v4f kLow = (v4f){-3e38f, -3e38f, -3e38f, -3e38f};
     v4f p1c = kLow, p1d = kLow, p2c = kLow, p2d = kLow; // the two row blocks whose folds are still owed
-    // 32 MFMAs over two candidate blocks with the folds of two row blocks ago between them and (EXPAND) one spread of the
-    // next source block per row block: the pattern is then one matrix + up to three vector instructions
-    auto mma2 = [&](auto expand_c, const Ops &o, const Src &sr, Exp &ex) {
-        constexpr bool kExpand = decltype(expand_c)::value;
+    // Half a step: 32 MFMAs over the two candidate blocks in `o`, the folds of two row blocks ago between them, and behind
+    // row blocks 0..2 the six LDS reads of the NEXT two blocks into `n` (offset RD), two per row block: a burst of six
+    // ds_read_b128 in front of the MFMAs held the wave's issue for ~50 cycles per half, two in a gap cost ~3
+    // (MI355X_MICROARCH.md, LDS: 'issued between MFMAs').  The FIRST half of a step also carries the expansion of the
+    // source block `sr` into `ex` -- one dword per row block, the popcount met across the four lanes of a keypoint by
+    // v_permlane16_swap / v_permlane32_swap (vector instructions; the __shfl_xor of the prologue is two ds_bpermute round
+    // trips, which stood exposed in the middle of every step), the key in row block 4; the SECOND half writes `ex` into
+    // the ring at offset WR behind row blocks 3..5.  Everything that touches LDS is hand-written asm between two
+    // sched_barriers, so it sits exactly where it is written.
+    auto mma2 = [&](auto first_c, auto rd_c, auto wr_c, const Ops &o, Ops &n, const Src &sr, Exp &ex) {
+        constexpr bool kFirst = decltype(first_c)::value;
+        constexpr int RD = decltype(rd_c)::value, WR = decltype(wr_c)::value;
         const v8i b0 = (v8i){(int)o.q0.x, (int)o.q0.y, (int)o.q0.z, (int)o.q0.w, 0, 0, 0, 0};
         const v8i b1 = (v8i){(int)o.q1.x, (int)o.q1.y, (int)o.q1.z, (int)o.q1.w, 0, 0, 0, 0};
         const v8i d0 = (v8i){(int)o.r0.x, (int)o.r0.y, (int)o.r0.z, (int)o.r0.w, 0, 0, 0, 0};
         const v8i d1 = (v8i){(int)o.r1.x, (int)o.r1.y, (int)o.r1.z, (int)o.r1.w, 0, 0, 0, 0};
-#pragma unroll
-        for (int m = 0; m < RB; m++) {
+        auto row_block = [&](auto m_c) { // (a constant m: sched_group_barrier takes literals only)
+            constexpr int m = decltype(m_c)::value;
             v4f &fold = best[(m + RB - 2) % RB]; // m = 0, 1: the previous pass's last two row blocks
             v4f acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m][0], b0, o.cv, 4, 4, 0, 0, 0, 0);
             fold[0] = __builtin_fmaxf(__builtin_fmaxf(fold[0], p2c[0]), p2d[0]); // v_max3_f32
@@ -396,42 +439,71 @@ match_tile_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *__r
             p2d = p1d;
             p1c = acc;
             p1d = acd;
-            if (kExpand) { // spread number m of the eight
-                const uint32_t w = m < 4 ? sr.w0 : sr.w1;
-                const uint32_t v = spread_bits_e2m1(w >> (8 * (m & 3)));
-                if (m == 0) ex.f0.x = v;
-                if (m == 1) ex.f0.y = v;
-                if (m == 2) ex.f0.z = v;
-                if (m == 3) ex.f0.w = v;
-                if (m == 4) ex.f1.x = v;
-                if (m == 5) ex.f1.y = v;
-                if (m == 6) ex.f1.z = v;
-                if (m == 7) ex.f1.w = v;
+            if (kFirst) { // piece m of the expansion
+                if (m == 0) ex.f0.x = tile_cand_dword<0>(sr.w0), ex.pc = __popc(sr.w0) + __popc(sr.w1);
+                if (m == 1) ex.f0.y = tile_cand_dword<1>(sr.w0), ex.pc = sum_lanes_xor16(ex.pc);
+                if (m == 2) ex.f0.z = tile_cand_dword<2>(sr.w0), ex.pc = sum_lanes_xor32(ex.pc);
+                if (m == 3) ex.f0.w = tile_cand_dword<3>(sr.w0);
+                if (m == 4) ex.f1.x = tile_cand_dword<0>(sr.w1), ex.key = -(float)(ex.pc * kMmaS + sr.kp) * kKeyUnit;
+                if (m == 5) ex.f1.y = tile_cand_dword<1>(sr.w1), ex.key = sr.kp >= 0 ? ex.key : -1e30f; // = column_key()
+                if (m == 6) ex.f1.z = tile_cand_dword<2>(sr.w1);
+                if (m == 7) ex.f1.w = tile_cand_dword<3>(sr.w1);
             }
-#pragma unroll
-            for (int g4 = 0; g4 < 4; g4++) { // the emitted order: one matrix instruction, then the vector instructions due
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, kExpand ? 2 : 1, 0);
-            }
+            // the emitted order: one matrix instruction, then the vector instructions due -- a fold, and the piece's
+            // instructions (kPiece[m] of them) dealt out over the four gaps
+            constexpr int kPiece[8] = {3, 4, 4, 2, 4, 3, 1, 2};
+            constexpr int extra = kFirst ? kPiece[m] : 0;
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 1 + (extra + 3) / 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 1 + (extra + 2) / 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 1 + (extra + 1) / 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 1 + extra / 4, 0);
             __builtin_amdgcn_sched_barrier(0); // nothing crosses from one row block to the next
-        }
+            if (m == 0)
+                asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
+                             : "=&v"(n.q0), "=&v"(n.q1)
+                             : "v"(lds16), "n"(RD), "n"(RD + 1024)
+                             : "memory");
+            if (m == 1)
+                asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%5"
+                             : "=&v"(n.cv), "=&v"(n.r0)
+                             : "v"(ldsk), "v"(lds16), "n"(RD + 2048), "n"(RD + kTileBlk)
+                             : "memory");
+            if (m == 2)
+                asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%5"
+                             : "=&v"(n.r1), "=&v"(n.dv)
+                             : "v"(lds16), "v"(ldsk), "n"(RD + kTileBlk + 1024), "n"(RD + kTileBlk + 2048)
+                             : "memory");
+            if (!kFirst && m == 3) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(wr16), "v"(ex.f0), "n"(WR) : "memory");
+            if (!kFirst && m == 4) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(wr16), "v"(ex.f1), "n"(WR + 1024) : "memory");
+            if (!kFirst && m == 5) {
+                // the key tuple: the four lanes of a keypoint hold the same key and write it to the same 16 bytes -- no branch
+                // (a divergent `if (lane < 16)` here split the loop body into blocks and cost the kernel 335 spilled registers)
+                const v4f k4 = (v4f){ex.key, ex.key, ex.key, ex.key};
+                asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(wrk), "v"(k4), "n"(WR + 2048) : "memory");
+            }
+            if (m <= 2 || (!kFirst && m <= 5)) __builtin_amdgcn_sched_barrier(0);
+        };
+        row_block(std::integral_constant<int, 0>{});
+        row_block(std::integral_constant<int, 1>{});
+        row_block(std::integral_constant<int, 2>{});
+        row_block(std::integral_constant<int, 3>{});
+        row_block(std::integral_constant<int, 4>{});
+        row_block(std::integral_constant<int, 5>{});
+        row_block(std::integral_constant<int, 6>{});
+        row_block(std::integral_constant<int, 7>{});
     };
-    // the expansion of a source block: eight 8-bit -> 8-nibble spreads, the popcount met across the four lanes of a keypoint
+    // the expansion of a source block in one piece (the prologue's)
     auto expand = [&](const Src &sr) {
         Exp e;
-        e.f0 = spread_word_e2m1(sr.w0);
-        e.f1 = spread_word_e2m1(sr.w1);
-        int pc = __popc(sr.w0) + __popc(sr.w1);
-        pc += __shfl_xor(pc, 16);
-        pc += __shfl_xor(pc, 32);
-        e.key = sr.kp >= 0 ? -(float)(pc * kMmaS + sr.kp) * kKeyUnit : -1e30f;
+        e.f0 = tile_cand_word(sr.w0);
+        e.f1 = tile_cand_word(sr.w1);
+        e.pc = sum_lanes_xor32(sum_lanes_xor16(__popc(sr.w0) + __popc(sr.w1)));
+        e.key = column_key(e.pc, sr.kp);
         return e;
-    };
-    auto expand_key = [&](const Src &sr) {
-        int pc = __popc(sr.w0) + __popc(sr.w1);
-        pc += __shfl_xor(pc, 16);
-        pc += __shfl_xor(pc, 32);
-        return sr.kp >= 0 ? -(float)(pc * kMmaS + sr.kp) * kKeyUnit : -1e30f;
     };
     Ops P, Q;
     Exp E;
@@ -447,7 +519,7 @@ match_tile_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *__r
         const int kp = row0 + m * 16 + kq;
         const bool in = kp < nA; // (rows past the count: zero fragments, results discarded below)
         const uint32_t w0 = in ? recA[(size_t)kp * 13 + 5 + wq] : 0u, w1 = in ? recA[(size_t)kp * 13 + 9 + wq] : 0u;
-        const u32x4 f0 = spread_word_e2m1(w0), f1 = spread_word_e2m1(w1);
+        const u32x4 f0 = tile_query_word(w0), f1 = tile_query_word(w1);
         a[m][0] = (v8i){(int)f0.x, (int)f0.y, (int)f0.z, (int)f0.w, 0, 0, 0, 0};
         a[m][1] = (v8i){(int)f1.x, (int)f1.y, (int)f1.z, (int)f1.w, 0, 0, 0, 0};
         int pc = __popc(w0) + __popc(w1);
@@ -463,20 +535,17 @@ match_tile_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *__r
     // LDS reads are requested 32 MFMAs before they are needed; the expansion rides in the first half's MFMA gaps.
     auto step = [&](auto slot_c, int t) {
         constexpr int s = decltype(slot_c)::value;
-        landed(P);                                                       // blocks 0, 1: requested in the previous step
-        read2(std::integral_constant<int, s * kTileSlot + 2 * kTileBlk>{}, Q, lds16, ldsk);
+        typedef std::integral_constant<int, s * kTileSlot> this_slot;
+        landed(P); // blocks 0, 1: requested in the previous step
         const Src cur = nx0; // the source of step t + 2, fetched two steps ago
         nx0 = nx1;
         nx1 = fetch(t + 4);
         __builtin_amdgcn_sched_barrier(0);
-        mma2(std::true_type{}, P, cur, E);
-        E.key = expand_key(cur);
+        mma2(std::true_type{}, std::integral_constant<int, s * kTileSlot + 2 * kTileBlk>{}, this_slot{}, P, Q, cur, E);
         landed(Q);
         asm volatile("s_barrier" ::: "memory");
-        store(slot_c, E); // step t + 2 into the slot everybody has just finished with
-        read2(std::integral_constant<int, ((s + 1) % kRing2) * kTileSlot>{}, P, lds16, ldsk);
-        __builtin_amdgcn_sched_barrier(0);
-        mma2(std::false_type{}, Q, cur, E);
+        // blocks 0, 1 of the other slot into P, step t + 2 into the slot everybody has just finished with
+        mma2(std::false_type{}, std::integral_constant<int, ((s + 1) % kRing2) * kTileSlot>{}, this_slot{}, Q, P, cur, E);
     };
     int i = 0;
     for (; i + 2 <= S; i += 2) {
