@@ -314,6 +314,21 @@ __device__ __forceinline__ int sum_lanes_xor32(int x)
     const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
     return (int)(r[0] + r[1]);
 }
+// The maximum over the 16 lanes of a DPP row, in every lane of it, by four v_max_f32 with DPP operands: lanes ^ 1 and ^ 2 inside a
+// quad, then the mirrored half row (the other quad: all four of its lanes hold its maximum by now) and the mirrored row.  (The
+// __shfl_xor this replaces is a ds_bpermute_b32 round trip per exchange: 128 of them in a row were the kernel's epilogue.)
+template <int CTRL> __device__ __forceinline__ float max_with_dpp(float v)
+{
+    const int o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true);
+    return __builtin_fmaxf(v, __builtin_bit_cast(float, o));
+}
+__device__ __forceinline__ float max_over_row16(float v)
+{
+    v = max_with_dpp<0xB1>(v);  // quad_perm [1, 0, 3, 2]
+    v = max_with_dpp<0x4E>(v);  // quad_perm [2, 3, 0, 1]
+    v = max_with_dpp<0x141>(v); // row_half_mirror
+    return max_with_dpp<0x140>(v); // row_mirror
+}
 // colkey of candidate kp with |b| = pc (see (2) above); past the count (kp < 0): never wins
 __device__ __forceinline__ float column_key(int pc, int kp) { return kp >= 0 ? -(float)(pc * kMmaS + kp) * kKeyUnit : -1e30f; }
 __device__ __forceinline__ u32x4 tile_query_word(uint32_t w)
@@ -357,14 +372,18 @@ match_tile_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *__r
         uint32_t w0, w1;
         int kp; // candidate index, or -1 past the count (key -1e30: never wins)
     };
-    auto fetch = [&](int t) {
-        int lb = 4 * t + wv;
-        lb = lb < nBb ? lb : nBb - 1; // past the end: the last block again (maxima are idempotent)
-        const int kp = lb * 16 + kq;
-        const int kc = kp < nB ? kp : nB - 1; // (nB >= 1 here) a legal record for the load; the key marks it dead
+    // (blocks past the count clamp to the last record and carry dead keys: maxima are idempotent, a dead key never wins)
+    const unsigned char *__restrict__ recB8 = reinterpret_cast<const unsigned char *>(recB);
+    const uint32_t lane_off = 20u + 4u * (uint32_t)wq; // descriptor word wq of a record; word wq + 4 is 16 bytes on
+    int kp_next = wv * 16 + kq;                        // the candidate this lane fetches next: 64 on per step
+    auto fetch = [&]() {
+        const int kp = kp_next;
+        kp_next += 64;
+        const uint32_t kc = min((uint32_t)kp, (uint32_t)(nB - 1)); // (nB >= 1 here) a legal record for the load
+        const uint32_t off = kc * 52u + lane_off;                  // 32 bits: one frame's records are < 4 GB by far
         Src r;
-        r.w0 = recB[(size_t)kc * 13 + 5 + wq];
-        r.w1 = recB[(size_t)kc * 13 + 9 + wq];
+        r.w0 = *reinterpret_cast<const uint32_t *>(recB8 + off);
+        r.w1 = *reinterpret_cast<const uint32_t *>(recB8 + off + 16);
         r.kp = kp < nB ? kp : -1;
         return r;
     };
@@ -417,7 +436,7 @@ match_tile_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *__r
     // trips, which stood exposed in the middle of every step), the key in row block 4; the SECOND half writes `ex` into
     // the ring at offset WR behind row blocks 3..5.  Everything that touches LDS is hand-written asm between two
     // sched_barriers, so it sits exactly where it is written.
-    auto mma2 = [&](auto first_c, auto rd_c, auto wr_c, const Ops &o, Ops &n, const Src &sr, Exp &ex) {
+    auto mma2 = [&](auto first_c, auto rd_c, auto wr_c, const Ops &o, Ops &n, Src &sr, Exp &ex) {
         constexpr bool kFirst = decltype(first_c)::value;
         constexpr int RD = decltype(rd_c)::value, WR = decltype(wr_c)::value;
         const v8i b0 = (v8i){(int)o.q0.x, (int)o.q0.y, (int)o.q0.z, (int)o.q0.w, 0, 0, 0, 0};
@@ -449,10 +468,11 @@ match_tile_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *__r
                 if (m == 6) ex.f1.z = tile_cand_dword<2>(sr.w1);
                 if (m == 7) ex.f1.w = tile_cand_dword<3>(sr.w1);
             }
+            if (!kFirst && m == 6) sr = fetch(); // the buffer's next source: five vector instructions and the two loads
             // the emitted order: one matrix instruction, then the vector instructions due -- a fold, and the piece's
             // instructions (kPiece[m] of them) dealt out over the four gaps
             constexpr int kPiece[8] = {3, 4, 4, 2, 4, 3, 1, 2};
-            constexpr int extra = kFirst ? kPiece[m] : 0;
+            constexpr int extra = kFirst ? kPiece[m] : m == 6 ? 5 : 0;
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 1 + (extra + 3) / 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -461,6 +481,7 @@ match_tile_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *__r
             __builtin_amdgcn_sched_group_barrier(0x002, 1 + (extra + 1) / 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 1 + extra / 4, 0);
+            if (!kFirst && m == 6) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
             __builtin_amdgcn_sched_barrier(0); // nothing crosses from one row block to the next
             if (m == 0)
                 asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
@@ -507,24 +528,34 @@ match_tile_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *__r
     };
     Ops P, Q;
     Exp E;
-    // prologue: steps 0 and 1 expanded into the two slots, the sources of steps 2 and 3 requested
-    store(std::integral_constant<int, 0>{}, expand(fetch(0)));
-    store(std::integral_constant<int, 1>{}, expand(fetch(1)));
-    Src nx0 = fetch(2), nx1 = fetch(3);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    read2(std::integral_constant<int, 0>{}, P, lds16, ldsk);
-    // the queries' fragments, expanded here (AFTER the ring's prologue: their 64 registers start to live only now)
+    // prologue.  Every global load of it is issued up front -- the queries' raw words (16 registers; their 64-register
+    // fragments are made after the ring's prologue) and the sources of steps 0..3 -- so the workgroup pays one memory
+    // latency, not three in a row (in-kernel stamps, profiles/r05_tile_stamps.txt: the prologue was 13 000 cycles of a
+    // workgroup's 85 000, the epilogue 18 600).
+    uint32_t qw0[RB], qw1[RB];
 #pragma unroll
     for (int m = 0; m < RB; m++) {
         const int kp = row0 + m * 16 + kq;
-        const bool in = kp < nA; // (rows past the count: zero fragments, results discarded below)
-        const uint32_t w0 = in ? recA[(size_t)kp * 13 + 5 + wq] : 0u, w1 = in ? recA[(size_t)kp * 13 + 9 + wq] : 0u;
+        const int kc = kp < nA ? kp : nA - 1; // (nA >= 1 here; rows past the count: zero fragments, results discarded below)
+        qw0[m] = recA[(size_t)kc * 13 + 5 + wq];
+        qw1[m] = recA[(size_t)kc * 13 + 9 + wq];
+    }
+    const Src s0 = fetch(), s1 = fetch();
+    Src nx0 = fetch();
+    Src nx1 = fetch();
+    // steps 0 and 1 expanded into the two slots
+    store(std::integral_constant<int, 0>{}, expand(s0));
+    store(std::integral_constant<int, 1>{}, expand(s1));
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    read2(std::integral_constant<int, 0>{}, P, lds16, ldsk);
+#pragma unroll
+    for (int m = 0; m < RB; m++) {
+        const bool in = row0 + m * 16 + kq < nA;
+        const uint32_t w0 = in ? qw0[m] : 0u, w1 = in ? qw1[m] : 0u;
         const u32x4 f0 = tile_query_word(w0), f1 = tile_query_word(w1);
         a[m][0] = (v8i){(int)f0.x, (int)f0.y, (int)f0.z, (int)f0.w, 0, 0, 0, 0};
         a[m][1] = (v8i){(int)f1.x, (int)f1.y, (int)f1.z, (int)f1.w, 0, 0, 0, 0};
-        int pc = __popc(w0) + __popc(w1);
-        pc += __shfl_xor(pc, 16);
-        pc += __shfl_xor(pc, 32);
+        const int pc = sum_lanes_xor32(sum_lanes_xor16(__popc(w0) + __popc(w1)));
         if (wq == 0) s_popA[wv * 128 + m * 16 + kq] = (uint16_t)pc;
     }
 #pragma unroll
@@ -533,26 +564,27 @@ match_tile_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *__r
     // slot in registers (and its own ring writes of the step before have completed: the same lgkmcnt(0)), so behind the
     // barrier slot s may take step t + 2, and the other slot, written a step ago, is complete for everybody.  Both halves'
     // LDS reads are requested 32 MFMAs before they are needed; the expansion rides in the first half's MFMA gaps.
-    auto step = [&](auto slot_c, int t) {
+    // The source block a step expands was fetched two steps earlier into one of TWO register buffers, refilled right after
+    // their use (step t: buffer t & 1 holds block 4 (t + 2) + w and takes block 4 (t + 4) + w in row block 6 of the second half).  Two buffers and a loop
+    // unrolled by two: no buffer ever changes registers, so the loads stay in flight across the loop's back-edge (three
+    // rotating values made hipcc copy them there, behind an s_waitcnt vmcnt(0) that cut the prefetch distance to one step).
+    auto step = [&](auto slot_c, Src &buf) {
         constexpr int s = decltype(slot_c)::value;
         typedef std::integral_constant<int, s * kTileSlot> this_slot;
         landed(P); // blocks 0, 1: requested in the previous step
-        const Src cur = nx0; // the source of step t + 2, fetched two steps ago
-        nx0 = nx1;
-        nx1 = fetch(t + 4);
         __builtin_amdgcn_sched_barrier(0);
-        mma2(std::true_type{}, std::integral_constant<int, s * kTileSlot + 2 * kTileBlk>{}, this_slot{}, P, Q, cur, E);
+        mma2(std::true_type{}, std::integral_constant<int, s * kTileSlot + 2 * kTileBlk>{}, this_slot{}, P, Q, buf, E);
         landed(Q);
         asm volatile("s_barrier" ::: "memory");
         // blocks 0, 1 of the other slot into P, step t + 2 into the slot everybody has just finished with
-        mma2(std::false_type{}, std::integral_constant<int, ((s + 1) % kRing2) * kTileSlot>{}, this_slot{}, Q, P, cur, E);
+        mma2(std::false_type{}, std::integral_constant<int, ((s + 1) % kRing2) * kTileSlot>{}, this_slot{}, Q, P, buf, E);
     };
     int i = 0;
     for (; i + 2 <= S; i += 2) {
-        step(std::integral_constant<int, 0>{}, i);
-        step(std::integral_constant<int, 1>{}, i + 1);
+        step(std::integral_constant<int, 0>{}, nx0);
+        step(std::integral_constant<int, 1>{}, nx1);
     }
-    if (i < S) step(std::integral_constant<int, 0>{}, i); // S is the same for the four waves: the barriers stay matched
+    if (i < S) step(std::integral_constant<int, 0>{}, nx0); // S is the same for the four waves: the barriers stay matched
     landed(P); // (the read of the slot after the last one: harmless, but it must have returned before the registers die)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -560,30 +592,35 @@ match_tile_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *__r
         best[RB - 1][r] = __builtin_fmaxf(__builtin_fmaxf(best[RB - 1][r], p1c[r]), p1d[r]);
     }
     // C/D layout: lane holds rows 4 * (lane >> 4) + r of each 16-row fragment, column class lane & 15: the row's maximum is
-    // the maximum over its 16 lanes
+    // the maximum over its 16 lanes, left in all of them.  Then every lane takes ONE row of each half of the row blocks --
+    // lane L: r = L & 3, m = ((L & 15) >> 2) + 4 h -- so the 128 results leave in two passes of 64 full lanes (one pass per
+    // (m, r) with one lane in sixteen writing was 32 branches, 32 LDS reads and 32 waits).
 #pragma unroll
     for (int m = 0; m < RB; m++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            float v = best[m][r];
-            v = fmaxf(v, __shfl_xor(v, 1));
-            v = fmaxf(v, __shfl_xor(v, 2));
-            v = fmaxf(v, __shfl_xor(v, 4));
-            v = fmaxf(v, __shfl_xor(v, 8));
-            const int i_q = row0 + m * 16 + 4 * (lane >> 4) + r;
-            if ((lane & 15) == 0 && i_q < cap) {
-                bool ok = i_q < nA && v > -1e29f;
-                int bj = -1, bd = -1;
-                if (ok) {
-                    const int nk = -(int)(v * (2 * kMmaS)); // S * (dist - |a_i|) + j
-                    bj = nk & (kMmaS - 1);
-                    bd = (int)s_popA[wv * 128 + m * 16 + 4 * (lane >> 4) + r] + (nk >> 14); // |a_i| from the prologue
-                    ok = bd <= max_dist;
-                }
-                out_idx[(size_t)pk * cap + i_q] = ok ? bj : -1;
-                if (out_dist) out_dist[(size_t)pk * cap + i_q] = ok ? bd : -1;
-            }
+        for (int r = 0; r < 4; r++) best[m][r] = max_over_row16(best[m][r]);
+    const int r_sel = lane & 3, m_sel = (lane & 15) >> 2;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        float x[4];
+#pragma unroll
+        for (int mm = 0; mm < 4; mm++) {
+            const v4f &b4 = best[4 * h + mm];
+            x[mm] = r_sel == 0 ? b4[0] : r_sel == 1 ? b4[1] : r_sel == 2 ? b4[2] : b4[3];
         }
+        const float v = m_sel == 0 ? x[0] : m_sel == 1 ? x[1] : m_sel == 2 ? x[2] : x[3];
+        const int q = (4 * h + m_sel) * 16 + 4 * (lane >> 4) + r_sel; // this lane's query of the wave's 128
+        const int i_q = row0 + q;
+        if (i_q < cap) {
+            bool ok = i_q < nA && v > -1e29f;
+            const int nk = -(int)(ok ? v * (2 * kMmaS) : 0.0f); // S * (dist - |a_i|) + j
+            const int bj = nk & (kMmaS - 1);
+            const int bd = (int)s_popA[wv * 128 + q] + (nk >> 14); // |a_i| from the prologue
+            ok = ok && bd <= max_dist;
+            out_idx[(size_t)pk * cap + i_q] = ok ? bj : -1;
+            if (out_dist) out_dist[(size_t)pk * cap + i_q] = ok ? bd : -1;
+        }
+    }
 }
 
 // Which form a call takes.  The tile kernel's workgroup holds 512 queries: a call needs at least one (pair, query tile)

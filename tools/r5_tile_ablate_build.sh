@@ -1,6 +1,7 @@
 #!/bin/bash
-# round 5: timing-only ablations of match_tile_kernel (WRONG results): nobar = no s_barrier in the loop, noexp = no in-loop expansion
-# arithmetic, nostore = no ring writes (the expansion and the source fetches die with them), noread = no ring reads in the loop.  Builds .variants/{nobar,noexp,nostore} from a
+# round 5: timing-only ablations of match_tile_kernel (WRONG results): nobar = no s_barrier in the loop, nofetch = no source loads in the
+# loop, nostore = no ring writes (the expansion and the source fetches die with them), noread = no ring reads in the loop, mfmaonly = none
+# of the three (MFMAs and folds on stale operands).  Builds .variants/<name> from a
 # scratch copy of the sources; run tools/r5_tile_ablate_run.sh through gpurun afterwards.
 set -e
 cd /root/repo
@@ -9,23 +10,37 @@ mk() { # name, sed expr
   NAME=$1; EXPR=$2
   W=$(mktemp -d /tmp/orbfe_v.XXXX); mkdir -p $W/jetracer-orbslam2_amd; cp -r include $W/; cp -r jetracer-orbslam2_amd/csrc $W/jetracer-orbslam2_amd/; rm -rf $W/jetracer-orbslam2_amd/csrc/.obj
   python3 - "$W/jetracer-orbslam2_amd/csrc/match_mfma.hip" "$NAME" <<'PY'
-import sys
+import sys, re
 p,name=sys.argv[1],sys.argv[2]
 s=open(p).read()
-if name=="nobar":
-    assert 'asm volatile("s_barrier" ::: "memory");' in s
-    s=s.replace('        asm volatile("s_barrier" ::: "memory");\n        store(slot_c, E);','        store(slot_c, E);')
-elif name=="noexp":
-    s=s.replace("        mma2(std::true_type{}, P, cur, E);\n        E.key = expand_key(cur);","        mma2(std::false_type{}, P, cur, E);\n        E.key = (float)cur.kp;")
-elif name=="noread":  # the ring is written but never read in the loop: the operands of the prologue's read serve every step
-    import re
-    a=s.index("    auto step = [&](auto slot_c, int t) {"); b=s.index("    int i = 0;\n    for (; i + 2 <= S; i += 2)")
-    body=s[a:b]
-    body=re.sub(r"        read2\(std::integral_constant<int, [^\n]*\n","",body)
-    body=body.replace("mma2(std::false_type{}, Q, cur, E);","mma2(std::false_type{}, P, cur, E);").replace("        landed(Q);\n","")
-    s=s[:a]+body+s[b:]
-elif name=="nostore":
-    s=s.replace("        store(slot_c, E); // step t + 2 into the slot everybody has just finished with\n","")
+def drop_barrier(s):
+    assert '        asm volatile("s_barrier" ::: "memory");\n        buf = fetch(t + 4);' in s
+    return s.replace('        asm volatile("s_barrier" ::: "memory");\n        buf = fetch(t + 4);', '        buf = fetch(t + 4);')
+def drop_fetch(s):
+    assert "        buf = fetch(t + 4);\n" in s
+    return s.replace("        buf = fetch(t + 4);\n", "")
+def drop_stores(s):
+    s, n = re.subn(r'            if \(!kFirst && m == [34]\) asm volatile\("ds_write_b128[^\n]*\n', "", s)
+    assert n == 2
+    a = s.index("            if (!kFirst && m == 5) {"); b = s.index("            if (m <= 2 || (!kFirst && m <= 5))")
+    return s[:a] + s[b:]
+def drop_reads(s):
+    a = s.index("            if (m == 0)\n                asm volatile(\"ds_read_b128"); b = s.index("            if (!kFirst && m == 3)")
+    return s[:a] + s[b:]
+if name == "nobar": s = drop_barrier(s)
+elif name == "nofetch": s = drop_fetch(s)
+elif name == "nostore": s = drop_stores(s)   # (the expansion and the fetches die with the stores)
+elif name == "noread": s = drop_reads(s)     # the operands of the prologue's read serve every step
+elif name == "mfmaonly": s = drop_barrier(drop_stores(drop_reads(s)))
+elif name == "stamps":  # clock64() at entry / loop start / loop end / exit of wave 0, written over out_dist (tools/r5_tile_stamps.py reads them)
+    s = s.replace("    // descriptor word `w` of record `kp` of frame f", "    const long long t_in = clock64();\n    // descriptor word `w` of record `kp` of frame f", 1)
+    s = s.replace("    int i = 0;\n    for (; i + 2 <= S; i += 2) {\n        step(std::integral_constant<int, 0>{}, i, nx0);", "    const long long t_loop = clock64();\n    int i = 0;\n    for (; i + 2 <= S; i += 2) {\n        step(std::integral_constant<int, 0>{}, i, nx0);", 1)
+    s = s.replace("    landed(P); // (the read of the slot after the last one", "    const long long t_done = clock64();\n    landed(P); // (the read of the slot after the last one", 1)
+    a = s.index("bool match_mfma_uses_tile(int n_pairs")
+    k = s.rindex("}\n", 0, s.rindex("// Which form a call takes", 0, a))
+    s = s[:k] + "    if (threadIdx.x == 0 && out_dist) {\n        long long *o = reinterpret_cast<long long *>(out_dist + (size_t)pk * cap + blk * 512);\n        o[0] = t_in; o[1] = t_loop; o[2] = t_done; o[3] = clock64();\n    }\n" + s[k:]
+    assert s.count("t_loop") == 2 and s.count("t_done") == 2
+else: raise SystemExit("unknown ablation " + name)
 open(p,'w').write(s)
 PY
   OUT=$ROOT/jetracer-orbslam2_amd/.variants/$NAME; mkdir -p $OUT
@@ -35,4 +50,4 @@ PY
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/liborbfe.so jetracer-orbslam2_amd/csrc/.obj/stage_kernels.o jetracer-orbslam2_amd/csrc/.obj/batch_kernels.o $OUT/mfma.o jetracer-orbslam2_amd/csrc/.obj/align_depth.o jetracer-orbslam2_amd/csrc/.obj/ingest.o jetracer-orbslam2_amd/csrc/.obj/wire_bson.o jetracer-orbslam2_amd/csrc/.obj/pose_host.o jetracer-orbslam2_amd/csrc/.obj/steer_table.o
   rm -rf $W $OUT/mfma.o; echo built $NAME
 }
-for v in ${@:-nobar noexp nostore noread}; do mk $v x; done
+for v in ${@:-nobar nofetch nostore noread mfmaonly}; do mk $v x; done
