@@ -14,11 +14,11 @@ import sys, re
 p,name=sys.argv[1],sys.argv[2]
 s=open(p).read()
 def drop_barrier(s):
-    assert '        asm volatile("s_barrier" ::: "memory");\n        buf = fetch(t + 4);' in s
-    return s.replace('        asm volatile("s_barrier" ::: "memory");\n        buf = fetch(t + 4);', '        buf = fetch(t + 4);')
+    assert s.count('        asm volatile("s_barrier" ::: "memory");\n') == 1
+    return s.replace('        asm volatile("s_barrier" ::: "memory");\n', '')
 def drop_fetch(s):
-    assert "        buf = fetch(t + 4);\n" in s
-    return s.replace("        buf = fetch(t + 4);\n", "")
+    assert "            if (!kFirst && m == 6) sr = fetch();" in s
+    return s.replace("            if (!kFirst && m == 6) sr = fetch();", "")
 def drop_stores(s):
     s, n = re.subn(r'            if \(!kFirst && m == [34]\) asm volatile\("ds_write_b128[^\n]*\n', "", s)
     assert n == 2
@@ -33,12 +33,12 @@ elif name == "nostore": s = drop_stores(s)   # (the expansion and the fetches di
 elif name == "noread": s = drop_reads(s)     # the operands of the prologue's read serve every step
 elif name == "mfmaonly": s = drop_barrier(drop_stores(drop_reads(s)))
 elif name == "stamps":  # clock64() at entry / loop start / loop end / exit of wave 0, written over out_dist (tools/r5_tile_stamps.py reads them)
-    s = s.replace("    // descriptor word `w` of record `kp` of frame f", "    const long long t_in = clock64();\n    // descriptor word `w` of record `kp` of frame f", 1)
-    s = s.replace("    int i = 0;\n    for (; i + 2 <= S; i += 2) {\n        step(std::integral_constant<int, 0>{}, i, nx0);", "    const long long t_loop = clock64();\n    int i = 0;\n    for (; i + 2 <= S; i += 2) {\n        step(std::integral_constant<int, 0>{}, i, nx0);", 1)
+    s = s.replace("    // descriptor word `w` of record `kp` of frame f", "    const long long t_in = clock64(), w_in = wall_clock64();\n    // descriptor word `w` of record `kp` of frame f", 1)
+    s = s.replace("    int i = 0;\n    for (; i + 2 <= S; i += 2) {\n        step(std::integral_constant<int, 0>{}, nx0);", "    const long long t_loop = clock64();\n    int i = 0;\n    for (; i + 2 <= S; i += 2) {\n        step(std::integral_constant<int, 0>{}, nx0);", 1)
     s = s.replace("    landed(P); // (the read of the slot after the last one", "    const long long t_done = clock64();\n    landed(P); // (the read of the slot after the last one", 1)
     a = s.index("bool match_mfma_uses_tile(int n_pairs")
     k = s.rindex("}\n", 0, s.rindex("// Which form a call takes", 0, a))
-    s = s[:k] + "    if (threadIdx.x == 0 && out_dist) {\n        long long *o = reinterpret_cast<long long *>(out_dist + (size_t)pk * cap + blk * 512);\n        o[0] = t_in; o[1] = t_loop; o[2] = t_done; o[3] = clock64();\n    }\n" + s[k:]
+    s = s[:k] + "    if (threadIdx.x == 0 && out_dist) {\n        long long *o = reinterpret_cast<long long *>(out_dist + (size_t)pk * cap + blk * 512);\n        o[0] = t_in; o[1] = t_loop; o[2] = t_done; o[3] = clock64(); o[4] = w_in; o[5] = wall_clock64();\n    }\n" + s[k:]
     assert s.count("t_loop") == 2 and s.count("t_done") == 2
 else: raise SystemExit("unknown ablation " + name)
 open(p,'w').write(s)
