@@ -295,6 +295,10 @@ constexpr int kPxDw = kPxW / 4;                      // 18 dwords per row
 constexpr int kScW = kTileW + 2, kScH = kTileH + 2; // 66 x 66 score tile (1-px halo)
 constexpr int kScPitch = kScW + 2;                   // 68
 constexpr int kMaxLdsCells = (kTileW / 4) * (kTileH / 4);
+#ifndef ORBFE_DETECT_TILES_PER_WG
+#define ORBFE_DETECT_TILES_PER_WG 4
+#endif
+constexpr int kDetectTilesPerWg = ORBFE_DETECT_TILES_PER_WG; // consecutive tile-list entries a batch-path workgroup takes (detect_tile_kernel)
 
 // ---- compass pre-test on the four pixels of a dword AT ONCE, bytes in place (round 3).  Rounds 1-2 unpacked the
 // bytes into pairs of 16-bit lanes for v_pk_min/max/sub_u16: 50 instructions per dword, 27 of them at the packed
@@ -422,7 +426,7 @@ struct StageTiles {
 template <bool STAGE, int ARC>
 __global__ void __launch_bounds__(256)
 detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc *__restrict__ tiles,
-                   uint32_t *__restrict__ cellkey, int tile_first, int tile_step, StageTiles st)
+                   uint32_t *__restrict__ cellkey, int tile_first, int tile_step, int n_items, StageTiles st)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_px32[kPxH * kPxDw];
     __shared__ __attribute__((aligned(16))) uint16_t s_sc[kScH * kScPitch];
@@ -442,110 +446,139 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
     __shared__ int s_qcount;
     __shared__ uint32_t s_key[kMaxLdsCells];
 
-    int f, tile_id;
-    if (!frame_item(g, &f, &tile_id)) return;
-    TileDesc td;
-    if (STAGE) {
-        int lvl = 0;
+    int f, item;
+    if (!frame_item(g, &f, &item)) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint8_t *s_px = reinterpret_cast<const uint8_t *>(s_px32);
+    // A workgroup takes kT consecutive entries of its shard of the tile list, one after the other, and loads tile u + 1's
+    // pixels into registers while it works on tile u (r5: in-kernel stamps, profiles/r05_phase_stamps.txt, showed a workgroup
+    // waiting 26 % of its 7.7 us for the tile's round trip to memory at its head -- six workgroups per CU hide most of that,
+    // not all: vector issue stood at 0.73 of its ceiling).  The stage API keeps one tile per workgroup.
+    constexpr int kT = STAGE ? 1 : kDetectTilesPerWg;
+    const int tile0 = item * kT;
+    const int n_here = n_items - tile0 < kT ? n_items - tile0 : kT; // (>= 1: the grid is ceil(n_items / kT) wide)
+    auto tile_desc = [&](int u) {
+        if (STAGE) {
+            const int tile_id = tile0 + u;
+            int lvl = 0;
 #pragma unroll
-        for (int i = 1; i < 8; i++) lvl += (i < g.Ld && tile_id >= st.first[i]) ? 1 : 0;
-        const int t = tile_id - st.first[lvl], tyy = t / st.tiles_x[lvl];
-        td = TileDesc{(int16_t)lvl, (int16_t)(t - tyy * st.tiles_x[lvl]), (int16_t)tyy, 0};
-    } else {
+            for (int i = 1; i < 8; i++) lvl += (i < g.Ld && tile_id >= st.first[i]) ? 1 : 0;
+            const int t = tile_id - st.first[lvl], tyy = t / st.tiles_x[lvl];
+            return TileDesc{(int16_t)lvl, (int16_t)(t - tyy * st.tiles_x[lvl]), (int16_t)tyy, 0};
+        }
         // shard: every tile_step-th tile.  The index is wave-uniform and the list is never written by a kernel: read it
         // through the constant address space, i.e. with ONE s_load_dwordx2 (as a global load it was two vector loads
         // and two v_readfirstlane at the head of every wave)
-        td = load_tile_desc(tiles, tile_first + tile_id * tile_step);
-    }
-    const int l = td.level;
-    const int W = g.lv[l].w, H = g.lv[l].h, P = g.lv[l].pitch;
-    const uint8_t *img = pyr + (size_t)f * g.frame_stride + g.lv[l].offset;
-    const int x0 = td.tx * kTileW, y0 = td.ty * kTileH;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const uint8_t *s_px = reinterpret_cast<const uint8_t *>(s_px32);
-
+        return load_tile_desc(tiles, tile_first + (tile0 + u) * tile_step);
+    };
     // ---- A: pixel tile as dwords (x0 - 4 is dword aligned; rows are 64-byte aligned).  Dword i of
     //         the tile = (row i / 18, group i % 18); i advances by 256 per trip = 14 rows + 4 groups
-    //         with one carry, so there is no division; tiles that lie inside the image (with their
-    //         halo) skip the range tests.
-    {
-        // batch path: the context's pyramid has guard bands, every tile loads without range tests.  Stage API
-        // (caller-owned levels): only tiles that lie inside the image with their halo do.
-        const bool all_in = !STAGE || (x0 >= 4 && x0 + kTileW + 4 <= P && y0 >= 4 && y0 + kTileH + 4 <= H); // uniform
+    //         with one carry, so there is no division.  Batch path: the context's pyramid has guard bands, every tile loads
+    //         without range tests, every load is unconditional, so all kLoadTrips requests of a thread are in
+    //         flight together (a conditional load is followed by its own s_waitcnt vmcnt(0): six memory
+    //         latencies in a row).  Lanes past the tile's last dword re-load their first one.
+    constexpr int kLoadTrips = (kPxH * kPxDw + 255) / 256;
+    uint32_t pxv[kLoadTrips];
+    auto load_tile = [&](const TileDesc &t) {
+        const int P = g.lv[t.level].pitch;
+        const uint8_t *img = pyr + (size_t)f * g.frame_stride + g.lv[t.level].offset;
+        const int x0 = t.tx * kTileW, y0 = t.ty * kTileH;
         int r = tid / kPxDw, q = tid - r * kPxDw;
-        uint32_t off = (uint32_t)(__mul24(y0 - 4 + r, P) + x0 - 4 + 4 * q); // wraps harmlessly when unused
+        uint32_t off = (uint32_t)(__mul24(y0 - 4 + r, P) + x0 - 4 + 4 * q);
         const uint32_t dstep = (uint32_t)((256 / kPxDw) * P + 4 * (256 % kPxDw));
-        constexpr int kLoadTrips = (kPxH * kPxDw + 255) / 256;
-        if (all_in) {
-            // interior tile: every load is unconditional, so all kLoadTrips requests of a thread are in
-            // flight together (a conditional load is followed by its own s_waitcnt vmcnt(0): six memory
-            // latencies in a row).  Lanes past the tile's last dword re-load their first one.
-            uint32_t v[kLoadTrips];
-            // rows above the level's first one give a NEGATIVE offset (guard band / previous level): the base moves
-            // up by 4 rows + 4 bytes (scalar arithmetic) so that every lane offset is a non-negative 32-bit number --
-            // the SGPR-base form of the load, no sign extension and no 64-bit vector add per load
-            const uint8_t *img0 = img - (ptrdiff_t)(4 * P + 4);
-            off += (uint32_t)(4 * P + 4);
-            const uint32_t off0 = off;
+        // rows above the level's first one give a NEGATIVE offset (guard band / previous level): the base moves
+        // up by 4 rows + 4 bytes (scalar arithmetic) so that every lane offset is a non-negative 32-bit number --
+        // the SGPR-base form of the load, no sign extension and no 64-bit vector add per load
+        const uint8_t *img0 = img - (ptrdiff_t)(4 * P + 4);
+        off += (uint32_t)(4 * P + 4);
+        const uint32_t off0 = off;
 #pragma unroll
-            for (int t = 0; t < kLoadTrips; t++) {
-                const bool in = 256 * (t + 1) <= kPxH * kPxDw || 256 * t + tid < kPxH * kPxDw;
-                v[t] = *reinterpret_cast<const uint32_t *>(img0 + (in ? off : off0));
-                off += dstep;
-                q += 256 % kPxDw;
-                if (q >= kPxDw) { // carry into the next row
-                    q -= kPxDw;
-                    off += (uint32_t)(P - 4 * kPxDw);
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < kLoadTrips; t++)
-                if (256 * (t + 1) <= kPxH * kPxDw || 256 * t + tid < kPxH * kPxDw) s_px32[256 * t + tid] = v[t];
-        } else {
-#pragma unroll
-            for (int i0 = 0; i0 < kPxH * kPxDw; i0 += 256) {
-                const int i = i0 + tid;
-                if (i0 + 256 <= kPxH * kPxDw || i < kPxH * kPxDw) {
-                    uint32_t v = 0;
-                    const int gy = y0 - 4 + r, gx = x0 - 4 + 4 * q;
-                    if (gy >= 0 && gy < H && gx >= 0 && gx < P) v = *reinterpret_cast<const uint32_t *>(img + off);
-                    s_px32[i] = v;
-                }
-                off += dstep;
-                r += 256 / kPxDw;
-                q += 256 % kPxDw;
-                if (q >= kPxDw) { // carry into the next row
-                    q -= kPxDw;
-                    r += 1;
-                    off += (uint32_t)(P - 4 * kPxDw);
-                }
+        for (int t2 = 0; t2 < kLoadTrips; t2++) {
+            const bool in = 256 * (t2 + 1) <= kPxH * kPxDw || 256 * t2 + tid < kPxH * kPxDw;
+            pxv[t2] = *reinterpret_cast<const uint32_t *>(img0 + (in ? off : off0));
+            off += dstep;
+            q += 256 % kPxDw;
+            if (q >= kPxDw) { // carry into the next row
+                q -= kPxDw;
+                off += (uint32_t)(P - 4 * kPxDw);
             }
         }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int t2 = 0; t2 < kLoadTrips; t2++)
+            if (256 * (t2 + 1) <= kPxH * kPxDw || 256 * t2 + tid < kPxH * kPxDw) s_px32[256 * t2 + tid] = pxv[t2];
+    };
+    auto zero_scores = [&]() {
         static_assert((kScH * kScPitch * 2) % 16 == 0, "score tile is zeroed with 16-byte stores");
         constexpr int kScQuads = kScH * kScPitch / 8; // 561 stores: two full rounds and a short one, no loop
         static_assert(kScQuads > 512 && kScQuads <= 768, "score tile zeroing is unrolled for 3 rounds");
         reinterpret_cast<uint4 *>(s_sc)[tid] = make_uint4(0u, 0u, 0u, 0u);
         reinterpret_cast<uint4 *>(s_sc)[tid + 256] = make_uint4(0u, 0u, 0u, 0u);
         if (tid < kScQuads - 512) reinterpret_cast<uint4 *>(s_sc)[tid + 512] = make_uint4(0u, 0u, 0u, 0u);
+    };
+    TileDesc td = tile_desc(0);
+    // stage API (caller-owned levels): only tiles that lie inside the image with their halo load without range tests
+    const bool all_in = !STAGE || (td.tx * kTileW >= 4 && td.tx * kTileW + kTileW + 4 <= g.lv[td.level].pitch && td.ty * kTileH >= 4 &&
+                                   td.ty * kTileH + kTileH + 4 <= g.lv[td.level].h); // uniform
+    if (all_in) {
+        load_tile(td);
+        store_tile();
+    } else {
+        const int P = g.lv[td.level].pitch, H = g.lv[td.level].h;
+        const uint8_t *img = pyr + (size_t)f * g.frame_stride + g.lv[td.level].offset;
+        const int x0 = td.tx * kTileW, y0 = td.ty * kTileH;
+        int r = tid / kPxDw, q = tid - r * kPxDw;
+        uint32_t off = (uint32_t)(__mul24(y0 - 4 + r, P) + x0 - 4 + 4 * q); // wraps harmlessly when unused
+        const uint32_t dstep = (uint32_t)((256 / kPxDw) * P + 4 * (256 % kPxDw));
+#pragma unroll
+        for (int i0 = 0; i0 < kPxH * kPxDw; i0 += 256) {
+            const int i = i0 + tid;
+            if (i0 + 256 <= kPxH * kPxDw || i < kPxH * kPxDw) {
+                uint32_t v = 0;
+                const int gy = y0 - 4 + r, gx = x0 - 4 + 4 * q;
+                if (gy >= 0 && gy < H && gx >= 0 && gx < P) v = *reinterpret_cast<const uint32_t *>(img + off);
+                s_px32[i] = v;
+            }
+            off += dstep;
+            r += 256 / kPxDw;
+            q += 256 % kPxDw;
+            if (q >= kPxDw) { // carry into the next row
+                q -= kPxDw;
+                r += 1;
+                off += (uint32_t)(P - 4 * kPxDw);
+            }
+        }
     }
-    const int c = g.cell >> l, lc = ilog2(c);
-    const bool lds_cells = c >= 4;
-    const int lnc = 6 - lc, ncx = 1 << lnc, ncy = 1 << lnc; // cells per tile edge: 64 / c, c = 1 .. 64 a power of two
-    static_assert(kTileW == 64 && kTileH == 64, "cells per tile edge as a shift");
-    if (lds_cells)
-        for (int i = tid; i < ncx * ncy; i += 256) s_key[i] = 0u;
+    zero_scores();
+    if (tid < kMaxLdsCells) s_key[tid] = 0u; // (kMaxLdsCells = 256: the whole array, whatever the tile's cell count)
     if (tid == 0) s_qcount = 0;
-    __syncthreads();
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint16_t *q1 = s_q + 256; // the queue proper
     // slot of this wave's p-th positive: in place, inside the batches the wave itself has consumed (64 (wv + 4 j) ..)
     auto q2slot = [wv](int p) { return ((p >> 6) << 8) + (wv << 6) + (p & 63); };
-
-    // ---- B: compass pre-test, 4 pixels per lane; score-tile row r <-> image y0 - 1 + r,
-    //         pixel-tile column px <-> image x0 - 4 + px
     const uint32_t t2 = (uint32_t)g.threshold * 0x00010001u;
     const CompassConst ck = compass_const(g.threshold);
     constexpr int kCompass = ARC == 0 ? 2 : (ARC >= 12 ? 1 : 0);
+    static_assert(kMaxLdsCells == 256, "s_key is cleared by one store per thread");
+    for (int u = 0; u < n_here; u++) { // uniform
+    const int l = td.level;
+    const int W = g.lv[l].w, H = g.lv[l].h;
+    const int x0 = td.tx * kTileW, y0 = td.ty * kTileH;
+    const int c = g.cell >> l, lc = ilog2(c);
+    const bool lds_cells = c >= 4;
+    const int lnc = 6 - lc, ncx = 1 << lnc, ncy = 1 << lnc; // cells per tile edge: 64 / c, c = 1 .. 64 a power of two
+    static_assert(kTileW == 64 && kTileH == 64, "cells per tile edge as a shift");
+    __syncthreads(); // the tile's pixels, the cleared score tile, cell keys and queue counter are in LDS
+    // the next tile's pixels: requested now, stored behind the ring test (phase C is the last reader of this tile's)
+    TileDesc td_next = td;
+    if (kT > 1 && u + 1 < n_here) {
+        td_next = tile_desc(u + 1);
+        load_tile(td_next);
+    }
+
+    // ---- B: compass pre-test, 4 pixels per lane; score-tile row r <-> image y0 - 1 + r,
+    //         pixel-tile column px <-> image x0 - 4 + px
     int n1 = 0; // wave-uniform fill level of q1
     // Task = one dword group q (pixels px = 4q .. 4q+3) of score row r.  The first kMainTrips
     // trips cover the tile proper (rows 1..kTileH, groups 1..16, 16 rows per trip: the lane keeps its group, so
@@ -675,6 +708,7 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
         n2 += (int)__popcll(m);
     }
     __syncthreads(); // every wave's scores are in s_sc
+    if (kT > 1 && u + 1 < n_here) store_tile(); // (uniform) nobody reads this tile's pixels any more
 
     if (STAGE && st.resp[l]) { // the tile's part of the caller's response map, zeros included
         float *rp = st.resp[l];
@@ -708,15 +742,24 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
                 atomicMax(&cellkey[(size_t)f * g.K + cy * g.cells_x + cx], key);
         }
     }
-    if (!lds_cells) return;
-    __syncthreads();
-    for (int i = tid; i < ncx * ncy; i += 256) {
-        const uint32_t key = s_key[i];
-        if (key == 0u) continue;
-        const int cx = (x0 >> lc) + (i & (ncx - 1)), cy = (y0 >> lc) + (i >> lnc);
-        if (cx < g.cells_x && cy < g.cells_y)
-            atomicMax(&cellkey[(size_t)f * g.K + cy * g.cells_x + cx], key);
+    const bool more = kT > 1 && u + 1 < n_here; // uniform
+    if (!lds_cells && !more) return;
+    __syncthreads(); // the cell keys are final; every wave is done with the score tile and the queue
+    if (lds_cells) {
+        for (int i = tid; i < ncx * ncy; i += 256) {
+            const uint32_t key = s_key[i];
+            if (key == 0u) continue;
+            if (more) s_key[i] = 0u; // (the same thread that has just read it)
+            const int cx = (x0 >> lc) + (i & (ncx - 1)), cy = (y0 >> lc) + (i >> lnc);
+            if (cx < g.cells_x && cy < g.cells_y)
+                atomicMax(&cellkey[(size_t)f * g.K + cy * g.cells_x + cx], key);
+        }
     }
+    if (!more) return;
+    zero_scores();
+    if (tid == 0) s_qcount = 0;
+    td = td_next;
+    } // tiles of this workgroup
 }
 
 // ------------------------------------------------------------------------------------
@@ -1876,15 +1919,17 @@ match_batch_256_kernel(const Desc8 *__restrict__ mdesc, const float2 *__restrict
     }
 }
 
-static void launch_detect_tiles(const DeviceGeom &g, dim3 grid, hipStream_t stream, const uint8_t *pyr, const TileDesc *tiles,
+static void launch_detect_tiles(const DeviceGeom &g, int n_items, hipStream_t stream, const uint8_t *pyr, const TileDesc *tiles,
                                 uint32_t *cellkey, int tile_first, int tile_step)
 {
+    const unsigned wgs = (unsigned)((n_items + kDetectTilesPerWg - 1) / kDetectTilesPerWg); // per frame; the grid as frame_grid() lays it out
+    const dim3 grid = g.grid8 ? dim3(8u * wgs, (unsigned)(g.n_frames + 7) / 8u) : dim3(wgs, (unsigned)g.n_frames);
     const StageTiles st{};
     switch (g.arc) { // validated to 9..12 where the geometry is built
-    case 9: hipLaunchKernelGGL((detect_tile_kernel<false, 9>), grid, dim3(256), 0, stream, g, pyr, tiles, cellkey, tile_first, tile_step, st); break;
-    case 10: hipLaunchKernelGGL((detect_tile_kernel<false, 10>), grid, dim3(256), 0, stream, g, pyr, tiles, cellkey, tile_first, tile_step, st); break;
-    case 11: hipLaunchKernelGGL((detect_tile_kernel<false, 11>), grid, dim3(256), 0, stream, g, pyr, tiles, cellkey, tile_first, tile_step, st); break;
-    default: hipLaunchKernelGGL((detect_tile_kernel<false, 12>), grid, dim3(256), 0, stream, g, pyr, tiles, cellkey, tile_first, tile_step, st); break;
+    case 9: hipLaunchKernelGGL((detect_tile_kernel<false, 9>), grid, dim3(256), 0, stream, g, pyr, tiles, cellkey, tile_first, tile_step, n_items, st); break;
+    case 10: hipLaunchKernelGGL((detect_tile_kernel<false, 10>), grid, dim3(256), 0, stream, g, pyr, tiles, cellkey, tile_first, tile_step, n_items, st); break;
+    case 11: hipLaunchKernelGGL((detect_tile_kernel<false, 11>), grid, dim3(256), 0, stream, g, pyr, tiles, cellkey, tile_first, tile_step, n_items, st); break;
+    default: hipLaunchKernelGGL((detect_tile_kernel<false, 12>), grid, dim3(256), 0, stream, g, pyr, tiles, cellkey, tile_first, tile_step, n_items, st); break;
     }
 }
 
@@ -1944,7 +1989,7 @@ int launch_detect_stage(const orbfe_pyramid_level *lv, int n_levels, int thresho
     if (hipMemsetAsync(keys, 0, (size_t)g.K * sizeof(uint32_t), stream) != hipSuccess) return ORBFE_ERR_HIP;
     if (n_tiles > 0)
         hipLaunchKernelGGL((detect_tile_kernel<true, 0>), dim3(n_tiles, 1), dim3(256), 0, stream, g, lv[0].image,
-                           (const TileDesc *)nullptr, keys, 0, 1, st);
+                           (const TileDesc *)nullptr, keys, 0, 1, n_tiles, st);
     hipLaunchKernelGGL(stage_decode_kernel, dim3((g.K + 255) / 256), dim3(256), 0, stream, g.K, g.cells_x, g.cell, d_score,
                        d_pos, d_level);
     return hipGetLastError() == hipSuccess ? ORBFE_OK : ORBFE_ERR_HIP;
@@ -2728,7 +2773,7 @@ int orbfe_detect_batch_shard(orbfe_ctx *ctx, int n_frames, int shard_index, int 
     // levels and of busy / empty image regions)
     const int n_mine = ctx->n_tiles > shard_index ? (ctx->n_tiles - shard_index + shard_count - 1) / shard_count : 0;
     if (n_mine > 0)
-        launch_detect_tiles(with_frames(g, n_frames), frame_grid(n_mine, n_frames), S(stream), ctx->d_pyr, ctx->d_tiles, ctx->d_cellkey, shard_index,
+        launch_detect_tiles(with_frames(g, n_frames), n_mine, S(stream), ctx->d_pyr, ctx->d_tiles, ctx->d_cellkey, shard_index,
                             shard_count);
     CTX_LAUNCH_CHECK(ctx, "detect_batch");
     return ORBFE_OK;

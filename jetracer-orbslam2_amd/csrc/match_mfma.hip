@@ -623,16 +623,21 @@ match_tile_kernel(const orbfe_keypoint *__restrict__ records, const int32_t *__r
     }
 }
 
-// Which form a call takes.  The tile kernel's workgroup holds 512 queries: a call needs at least one (pair, query tile)
-// item per CU, or the 128-query forms fill the chip better (bench.py --mode match, ORBFE_MATCH=stream | tile: 15 pairs of
-// 8192 keypoints = 240 items: 0.090 ms streamed against 0.112 tiled; 255 pairs of 2000 = 1020 items: 0.1037 against 0.1022;
-// 255 pairs of 405 = 255 items: 0.0221 against 0.0177 -- short loops favour the single launch).  form: 0 = by size, 1 = the expand + stream forms,
-// 2 = the tile form (ORBFE_MATCH=stream|tile, read when the context is created: A/B timing, and the tests run both).
+// Which form a call takes.  The tile kernel's workgroup holds 512 queries and is the faster form whenever the chip is filled
+// (it needs no expansion pass and no scratch: 255 pairs of 2000 keypoints 0.075 ms against 0.104 streamed, 255 pairs of 405:
+// 0.009 against 0.022, 15 pairs of 8192: 0.077 against 0.092 -- bench.py --mode match, ORBFE_MATCH=stream | tile).  Small
+// calls are the exception (tools/r5_match_forms_sweep.py, profiles/r05_match_forms_sweep.txt): a tile workgroup runs a whole
+// candidate frame past its queries, so with fewer (pair, tile) items than half the CUs the 128-query workgroups of the
+// streamed forms spread the same work over more of the chip (1 pair of 2000: 0.010 ms against 0.022; the forms meet at ~128
+// items); and between 256 and 448 items the CUs that get a second tile workgroup run both at half pace (320 items of 4800
+// keypoints: 0.088 against 0.080).  form: 0 = by size, 1 = the expand + stream forms, 2 = the tile form (ORBFE_MATCH=stream|
+// tile, read when the context is created: A/B timing, and the tests run both).
 bool match_mfma_uses_tile(int n_pairs, int capP, int form)
 {
     if (form == 1) return false;
     if (form == 2) return true;
-    return (long long)n_pairs * ((capP + 511) / 512) >= 256;
+    const long long items = (long long)n_pairs * ((capP + 511) / 512);
+    return items >= 128 && !(items > 256 && items < 448);
 }
 
 void launch_match_mfma(const orbfe_keypoint *d_records, const int32_t *d_counts, int n_frames, int n_pairs, int first,
