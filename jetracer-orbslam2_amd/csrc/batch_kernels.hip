@@ -423,7 +423,7 @@ struct StageTiles {
 // ring-test batch).  ARC = 0 (the stage API): no arc is assumed at all -- the pre-test is the reference's own
 // (fast.cu:98-124) and every candidate looks its two masks up in the caller's table, so the result is the
 // reference's for ANY table contents (fast.cuh:25-26, :42-48 treat it as opaque).
-template <bool STAGE, int ARC>
+template <bool STAGE, int ARC, bool MULTI>
 __global__ void __launch_bounds__(256)
 detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc *__restrict__ tiles,
                    uint32_t *__restrict__ cellkey, int tile_first, int tile_step, int n_items, StageTiles st)
@@ -450,11 +450,13 @@ detect_tile_kernel(DeviceGeom g, const uint8_t *__restrict__ pyr, const TileDesc
     if (!frame_item(g, &f, &item)) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const uint8_t *s_px = reinterpret_cast<const uint8_t *>(s_px32);
-    // A workgroup takes kT consecutive entries of its shard of the tile list, one after the other, and loads tile u + 1's
-    // pixels into registers while it works on tile u (r5: in-kernel stamps, profiles/r05_phase_stamps.txt, showed a workgroup
-    // waiting 26 % of its 7.7 us for the tile's round trip to memory at its head -- six workgroups per CU hide most of that,
-    // not all: vector issue stood at 0.73 of its ceiling).  The stage API keeps one tile per workgroup.
-    constexpr int kT = STAGE ? 1 : kDetectTilesPerWg;
+    // MULTI: a workgroup takes kT consecutive entries of its shard of the tile list, one after the other, and loads tile
+    // u + 1's pixels into registers while it works on tile u (r5: in-kernel stamps, profiles/r05_phase_stamps.txt, showed a
+    // workgroup waiting 26 % of its 7.7 us for the tile's round trip to memory at its head -- six workgroups per CU hide most
+    // of that, not all).  Only launches of many rounds of workgroups take this form (launch_detect_tiles): a quarter of the
+    // workgroups, each four times as long, fill the chip worse when there are few (one 4K frame: 0.031 -> 0.050 ms).
+    constexpr int kT = MULTI ? kDetectTilesPerWg : 1;
+    static_assert(!(STAGE && MULTI), "the stage API keeps one tile per workgroup");
     const int tile0 = item * kT;
     const int n_here = n_items - tile0 < kT ? n_items - tile0 : kT; // (>= 1: the grid is ceil(n_items / kT) wide)
     auto tile_desc = [&](int u) {
@@ -1922,15 +1924,28 @@ match_batch_256_kernel(const Desc8 *__restrict__ mdesc, const float2 *__restrict
 static void launch_detect_tiles(const DeviceGeom &g, int n_items, hipStream_t stream, const uint8_t *pyr, const TileDesc *tiles,
                                 uint32_t *cellkey, int tile_first, int tile_step)
 {
-    const unsigned wgs = (unsigned)((n_items + kDetectTilesPerWg - 1) / kDetectTilesPerWg); // per frame; the grid as frame_grid() lays it out
-    const dim3 grid = g.grid8 ? dim3(8u * wgs, (unsigned)(g.n_frames + 7) / 8u) : dim3(wgs, (unsigned)g.n_frames);
     const StageTiles st{};
+    // tile groups (MULTI) when the launch is at least ~32 rounds of workgroups even then (1536 resident workgroups: 256 CUs x
+    // 6): C2 in steps of 4096 frames gains 2 % (640 k tiles), 256 frames (40 k tiles) LOSE 10 % to the coarser tail
+    const bool multi = (long long)n_items * g.n_frames >= 4ll * kDetectTilesPerWg * 12288;
+    const unsigned wgs = (unsigned)(multi ? (n_items + kDetectTilesPerWg - 1) / kDetectTilesPerWg : n_items); // per frame
+    const dim3 grid = g.grid8 ? dim3(8u * wgs, (unsigned)(g.n_frames + 7) / 8u) : dim3(wgs, (unsigned)g.n_frames); // = frame_grid()
+#define ORBFE_DETECT_LAUNCH(ARC)                                                                                                   \
+    do {                                                                                                                           \
+        if (multi)                                                                                                                 \
+            hipLaunchKernelGGL((detect_tile_kernel<false, ARC, true>), grid, dim3(256), 0, stream, g, pyr, tiles, cellkey,          \
+                               tile_first, tile_step, n_items, st);                                                                \
+        else                                                                                                                       \
+            hipLaunchKernelGGL((detect_tile_kernel<false, ARC, false>), grid, dim3(256), 0, stream, g, pyr, tiles, cellkey,         \
+                               tile_first, tile_step, n_items, st);                                                                \
+    } while (0)
     switch (g.arc) { // validated to 9..12 where the geometry is built
-    case 9: hipLaunchKernelGGL((detect_tile_kernel<false, 9>), grid, dim3(256), 0, stream, g, pyr, tiles, cellkey, tile_first, tile_step, n_items, st); break;
-    case 10: hipLaunchKernelGGL((detect_tile_kernel<false, 10>), grid, dim3(256), 0, stream, g, pyr, tiles, cellkey, tile_first, tile_step, n_items, st); break;
-    case 11: hipLaunchKernelGGL((detect_tile_kernel<false, 11>), grid, dim3(256), 0, stream, g, pyr, tiles, cellkey, tile_first, tile_step, n_items, st); break;
-    default: hipLaunchKernelGGL((detect_tile_kernel<false, 12>), grid, dim3(256), 0, stream, g, pyr, tiles, cellkey, tile_first, tile_step, n_items, st); break;
+    case 9: ORBFE_DETECT_LAUNCH(9); break;
+    case 10: ORBFE_DETECT_LAUNCH(10); break;
+    case 11: ORBFE_DETECT_LAUNCH(11); break;
+    default: ORBFE_DETECT_LAUNCH(12); break;
     }
+#undef ORBFE_DETECT_LAUNCH
 }
 
 // Stage API: cell keys (left in the caller's d_score buffer, 4 bytes per cell) -> the reference's feature
@@ -1988,7 +2003,7 @@ int launch_detect_stage(const orbfe_pyramid_level *lv, int n_levels, int thresho
     uint32_t *keys = reinterpret_cast<uint32_t *>(d_score); // 4 bytes per cell: the key, then (decode) the score
     if (hipMemsetAsync(keys, 0, (size_t)g.K * sizeof(uint32_t), stream) != hipSuccess) return ORBFE_ERR_HIP;
     if (n_tiles > 0)
-        hipLaunchKernelGGL((detect_tile_kernel<true, 0>), dim3(n_tiles, 1), dim3(256), 0, stream, g, lv[0].image,
+        hipLaunchKernelGGL((detect_tile_kernel<true, 0, false>), dim3(n_tiles, 1), dim3(256), 0, stream, g, lv[0].image,
                            (const TileDesc *)nullptr, keys, 0, 1, n_tiles, st);
     hipLaunchKernelGGL(stage_decode_kernel, dim3((g.K + 255) / 256), dim3(256), 0, stream, g.K, g.cells_x, g.cell, d_score,
                        d_pos, d_level);
