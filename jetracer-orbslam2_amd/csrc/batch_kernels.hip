@@ -1921,13 +1921,19 @@ match_batch_256_kernel(const Desc8 *__restrict__ mdesc, const float2 *__restrict
     }
 }
 
+// groups: 0 = by launch size, 1 = one tile per workgroup, 2 = tile groups (orbfe_ctx::detect_groups, ORBFE_DETECT_GROUPS)
+static bool detect_uses_groups(int n_items, int n_frames, int groups)
+{
+    if (groups) return groups == 2;
+    return (long long)n_items * n_frames >= 4ll * kDetectTilesPerWg * 12288;
+}
 static void launch_detect_tiles(const DeviceGeom &g, int n_items, hipStream_t stream, const uint8_t *pyr, const TileDesc *tiles,
-                                uint32_t *cellkey, int tile_first, int tile_step)
+                                uint32_t *cellkey, int tile_first, int tile_step, int groups)
 {
     const StageTiles st{};
     // tile groups (MULTI) when the launch is at least ~32 rounds of workgroups even then (1536 resident workgroups: 256 CUs x
     // 6): C2 in steps of 4096 frames gains 2 % (640 k tiles), 256 frames (40 k tiles) LOSE 10 % to the coarser tail
-    const bool multi = (long long)n_items * g.n_frames >= 4ll * kDetectTilesPerWg * 12288;
+    const bool multi = detect_uses_groups(n_items, g.n_frames, groups);
     const unsigned wgs = (unsigned)(multi ? (n_items + kDetectTilesPerWg - 1) / kDetectTilesPerWg : n_items); // per frame
     const dim3 grid = g.grid8 ? dim3(8u * wgs, (unsigned)(g.n_frames + 7) / 8u) : dim3(wgs, (unsigned)g.n_frames); // = frame_grid()
 #define ORBFE_DETECT_LAUNCH(ARC)                                                                                                   \
@@ -2637,6 +2643,11 @@ int orbfe_create(const orbfe_config *cfg, orbfe_ctx **out)
         if (v && !strcmp(v, "patch")) ctx->describe_patch = 2;
         else if (v && !strcmp(v, "tile")) ctx->describe_patch = -1; // (anything else: ignored)
     }
+    {
+        const char *v = getenv("ORBFE_DETECT_GROUPS"); // detect_tile_kernel's tile groups: by launch size, or forced (the tests run both)
+        if (v && !strcmp(v, "single")) ctx->detect_groups = 1;
+        else if (v && !strcmp(v, "multi")) ctx->detect_groups = 2;
+    }
     if (g.cap <= kMmaMaxKeypoints) { // scratch of the matrix-core matcher
         if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_mexp, B * ctx->cap_pad * 128);
         if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_mkey, B * ctx->cap_pad * sizeof(float));
@@ -2789,7 +2800,7 @@ int orbfe_detect_batch_shard(orbfe_ctx *ctx, int n_frames, int shard_index, int 
     const int n_mine = ctx->n_tiles > shard_index ? (ctx->n_tiles - shard_index + shard_count - 1) / shard_count : 0;
     if (n_mine > 0)
         launch_detect_tiles(with_frames(g, n_frames), n_mine, S(stream), ctx->d_pyr, ctx->d_tiles, ctx->d_cellkey, shard_index,
-                            shard_count);
+                            shard_count, ctx->detect_groups);
     CTX_LAUNCH_CHECK(ctx, "detect_batch");
     return ORBFE_OK;
 }
@@ -2986,8 +2997,9 @@ int orbfe_dispatch_info(const orbfe_ctx *ctx, int n_frames, int mode, int window
     case kMatchWindow256: match = "match_bucket_kernel+match_window_kernel"; break;
     case kMatchValu256: match = "match_gather_kernel+match_batch_256_kernel"; break;
     }
-    snprintf(buf, size, "pyramid=%s;detect=detect_tile_kernel<%d>;describe=select_kernel+%s%s;match=%s;match_examines=%s",
-             (g.W % 4 == 0) ? "pyramid_fused_kernel" : "blur_batch_kernel+halfsample_batch_kernel", g.arc, desc,
+    snprintf(buf, size, "pyramid=%s;detect=detect_tile_kernel<%d>%s;describe=select_kernel+%s%s;match=%s;match_examines=%s",
+             (g.W % 4 == 0) ? "pyramid_fused_kernel" : "blur_batch_kernel+halfsample_batch_kernel", g.arc,
+             detect_uses_groups(ctx->n_tiles, n_frames, ctx->detect_groups) ? "<groups of 4 tiles>" : "", desc,
              g.descriptor_level ? "<descriptor_level>" : "", match,
              match_path(ctx, n_frames, mode, window) == kMatchMfma || match_path(ctx, n_frames, mode, window) == kMatchValu256 ||
                      match_path(ctx, n_frames, mode, window) == kMatchRefLiteral

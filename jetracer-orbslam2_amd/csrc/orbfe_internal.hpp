@@ -252,6 +252,7 @@ struct orbfe_ctx {
     uint32_t *d_bd32 = nullptr;     // [max_batch][cap] reference-mode matcher: compressed 32-bit descriptors
     uint4 *d_mexp = nullptr;        // [max_batch][cap_pad][8]  MFMA matcher: descriptors as e2m1 fragments (cap <= 16384)
     float *d_mkey = nullptr;        // [max_batch][cap_pad]     MFMA matcher: -(popcount * 16384 + index)
+    int detect_groups = 0;          // 0: by launch size; 1 / 2: forced by ORBFE_DETECT_GROUPS=single / multi (detect_tile_kernel)
     int match_form = 0;             // 0: by call size; 1 / 2: forced by ORBFE_MATCH=stream / tile (match_mfma.hip)
     int cap_pad = 0;                // cap rounded up to 16
     int cellkey_clean = 0;          // frames whose cell keys the last pyramid build left cleared (0 once detect ran)

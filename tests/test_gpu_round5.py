@@ -615,3 +615,39 @@ def test_tile_matcher_fuzz(gpu, oracle_mod, monkeypatch):
             np.testing.assert_array_equal(dst[p, :cnt[p]], rd)
             assert (idx[p, cnt[p]:] == -1).all() and (dst[p, cnt[p]:] == -1).all()
         ctx.close()
+
+
+# ------------------------------------------------------------------ a5-a7: detect_tile_kernel's tile groups
+@pytest.mark.parametrize("groups", ["multi", "single"])
+def test_detect_tile_groups_through_the_earlier_rounds_tests(gpu, oracle_mod, monkeypatch, groups):
+    """Launches of many rounds of workgroups run detect_tile_kernel with four consecutive tile-list entries per workgroup (the
+    next tile's pixels prefetched under the current tile's phases); everything the tests launch is far too small for the size
+    rule to pick that form, so ORBFE_DETECT_GROUPS (read when a context is created) forces it -- and its opposite -- through
+    the extraction tests of round 1: every reference-mode size (tile lists of 1 .. 2700 entries, most not multiples of four,
+    levels mixed inside a group), the EXT modes, RGB input, tile-sharded detection (tile_step 3 and 8: a group's entries are
+    then 3 or 8 apart in the list) and the fuzz over random configurations."""
+    import test_gpu_parity as t1
+    torch, orbfe = gpu
+    monkeypatch.setenv("ORBFE_DETECT_GROUPS", groups)
+    probe = orbfe.Context(640, 480, levels=8, cell=8, min_arc=9, max_features=2000, max_batch=4)
+    assert ("groups of 4 tiles" in probe.dispatch_info(4, 1, -1)["detect"]) == (groups == "multi")
+    probe.close()
+    for w, h, levels in [(640, 480, 1), (640, 480, 6), (100, 70, 3), (640, 480, 10), (1280, 720, 9), (636, 476, 2), (130, 258, 8)]:
+        t1.test_extract_reference_mode(gpu, oracle_mod, w, h, levels)
+    for cfg in [dict(levels=8, cell=8, min_arc=9, max_features=2000), dict(levels=8, cell=16, min_arc=10, max_features=300, fast_threshold=20),
+                dict(levels=7, cell=64, min_arc=12, max_features=0), dict(levels=4, cell=32, min_arc=11, max_features=17, angle_in_radians=1)]:
+        t1.test_extract_ext_modes(gpu, oracle_mod, cfg)
+    t1.test_extract_rgb_fused(gpu, oracle_mod, 640, 480, 6)
+    t1.test_tile_sharded_detection_merges_exactly(gpu, oracle_mod, 3840, 2160, 12, 8)
+    t1.test_tile_sharded_detection_merges_exactly(gpu, oracle_mod, 640, 480, 6, 3)
+    t1.test_fuzz_random_configurations(gpu, oracle_mod)
+
+
+def test_detect_tile_groups_are_what_a_large_launch_runs(gpu, oracle_mod):
+    """The size rule itself: 4096 frames of the bench configuration dispatch to the grouped form, 256 do not (no compute here
+    beyond the context: the 4096-frame step is bench.py's, and the soak's c2 case checks its results)."""
+    torch, orbfe = gpu
+    ctx = orbfe.Context(640, 480, levels=8, cell=8, min_arc=9, max_features=2000, max_batch=2048)
+    assert "groups of 4 tiles" in ctx.dispatch_info(2048, 1, -1)["detect"]
+    assert "groups" not in ctx.dispatch_info(256, 1, -1)["detect"]
+    ctx.close()
