@@ -651,3 +651,52 @@ def test_detect_tile_groups_are_what_a_large_launch_runs(gpu, oracle_mod):
     assert "groups of 4 tiles" in ctx.dispatch_info(2048, 1, -1)["detect"]
     assert "groups" not in ctx.dispatch_info(256, 1, -1)["detect"]
     ctx.close()
+
+
+def test_a_bench_sized_step_against_the_oracle(gpu, oracle_mod):
+    """One extract + match over 2048 frames of the bench configuration -- the launch sizes at which the size rules pick detect's
+    tile groups and the tile matcher, which nothing else in the suite reaches by itself.  The batch is eight distinct frames
+    (dense scenes, a survey scene, noise, a constant frame) repeated in a fixed order, so eight oracle extractions and eight
+    oracle matches check every one of the 2048 record blocks and 2047 match lists, byte for byte."""
+    torch, orbfe = gpu
+    w, h, B, n = 640, 480, 2048, 2000
+    cfg = dict(levels=8, cell=8, min_arc=9, max_features=n)
+    base = [synth.frame(w, h, 900 + i, "rects", **synth.DENSE) for i in range(5)]
+    base += [synth.frame(w, h, 906, "rects", n_rects=96, min_size=6), FRAMES["uniform"](w, h), FRAMES["const"](w, h)]
+    base = np.stack(base)
+    ctx = orbfe.Context(w, h, max_batch=B, **cfg)
+    info = ctx.dispatch_info(B, 1, -1)
+    assert "groups of 4 tiles" in info["detect"] and info["match"] == "match_tile_kernel"
+    d_in = dev(torch, base)[torch.arange(B, device="cuda") % 8].contiguous()  # frame f = base[f % 8]
+    rec = torch.zeros(B * n * 52, dtype=torch.uint8, device="cuda")
+    cnt = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+    idx = torch.full(((B - 1) * n,), -7, dtype=torch.int32, device="cuda")
+    dst = torch.full(((B - 1) * n,), -7, dtype=torch.int32, device="cuda")
+    s = stream(torch)
+    ctx.extract(d_in.data_ptr(), w, w * h, B, rec.data_ptr(), cnt.data_ptr(), None, s)
+    ctx.match_batch(rec.data_ptr(), cnt.data_ptr(), B, 1, -1, 64, idx.data_ptr(), dst.data_ptr(), s)
+    torch.cuda.synchronize()
+    ocfg = oracle_mod.make_config(w, h, levels=8, cell=8, fast_threshold=13.0, min_arc=9, max_features=n,
+                                  angle_in_radians=0, descriptor_level=0)
+    refs = [oracle_mod.extract_frame(base[i], ocfg) for i in range(8)]
+    counts = cnt.cpu().numpy()
+    records = rec.cpu().numpy().reshape(B, n * 52)
+    for i in range(8):
+        want = np.zeros(n * 52, dtype=np.uint8)
+        rb = np.frombuffer(refs[i]["records"].tobytes(), dtype=np.uint8)
+        want[:rb.size] = rb
+        assert (counts[i::8] == refs[i]["count"]).all(), "counts of the copies of frame %d" % i
+        np.testing.assert_array_equal(records[i::8][:, :rb.size], np.broadcast_to(rb, (len(records[i::8]), rb.size)),
+                                      err_msg="records of the copies of frame %d" % i)
+    assert counts[7] == 0 and counts[0] == n
+    got_i, got_d = idx.cpu().numpy().reshape(B - 1, n), dst.cpu().numpy().reshape(B - 1, n)
+    for i in range(8):  # pair (f, f + 1) with f % 8 = i
+        a, b = refs[i], refs[(i + 1) % 8]
+        if a["count"] and b["count"]:
+            ri, rd = oracle_mod.match256(a["records"]["desc"], b["records"]["desc"], window=-1, max_dist=64)
+        else:
+            ri = rd = np.full(a["count"], -1, np.int32)
+        k = a["count"]
+        np.testing.assert_array_equal(got_i[i::8][:, :k], np.broadcast_to(ri, (len(got_i[i::8]), k)), err_msg="match indices, pair class %d" % i)
+        np.testing.assert_array_equal(got_d[i::8][:, :k], np.broadcast_to(rd, (len(got_d[i::8]), k)), err_msg="match distances, pair class %d" % i)
+        assert (got_i[i::8][:, k:] == -1).all()
