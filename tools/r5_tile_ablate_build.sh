@@ -40,6 +40,18 @@ elif name == "stamps":  # clock64() at entry / loop start / loop end / exit of w
     k = s.rindex("}\n", 0, s.rindex("// Which form a call takes", 0, a))
     s = s[:k] + "    if (threadIdx.x == 0 && out_dist) {\n        long long *o = reinterpret_cast<long long *>(out_dist + (size_t)pk * cap + blk * 512);\n        o[0] = t_in; o[1] = t_loop; o[2] = t_done; o[3] = clock64(); o[4] = w_in; o[5] = wall_clock64();\n    }\n" + s[k:]
     assert s.count("t_loop") == 2 and s.count("t_done") == 2
+elif name.startswith("dephodd"):  # as dephase, but the ODD workgroups of the first 512
+    n = int(name[7:] or 5)
+    s = s.replace("    // descriptor word `w` of record `kp` of frame f", "    { const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x; if (lin < 512u && (lin & 1u)) for (int z = 0; z < %d; z++) __builtin_amdgcn_s_sleep(127); }\n    // descriptor word `w` of record `kp` of frame f" % n, 1)
+    assert "s_sleep" in s
+elif name.startswith("dephx"):  # as dephase, but by the hardware's wave slot: the second wave of each SIMD (HW_ID wave id bit 0)
+    n = int(name[5:] or 5)
+    s = s.replace("    // descriptor word `w` of record `kp` of frame f", "    { const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x; const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11)); if (lin < 512u && (hw & 1u)) for (int z = 0; z < %d; z++) __builtin_amdgcn_s_sleep(127); }\n    // descriptor word `w` of record `kp` of frame f" % n, 1)
+    assert "s_sleep" in s
+elif name.startswith("dephase"):  # the second 256 workgroups of the launch start half a tile late: partners on a SIMD out of phase
+    n = int(name[7:] or 5)
+    s = s.replace("    // descriptor word `w` of record `kp` of frame f", "    { const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x; if (lin >= 256u && lin < 512u) for (int z = 0; z < %d; z++) __builtin_amdgcn_s_sleep(127); }\n    // descriptor word `w` of record `kp` of frame f" % n, 1)
+    assert "s_sleep" in s
 else: raise SystemExit("unknown ablation " + name)
 open(p,'w').write(s)
 PY
