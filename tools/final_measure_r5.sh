@@ -44,7 +44,7 @@ else
   timeout -k 10 200 python tools/ingest_probe.py 64 256 1024 > $OUT/ingest_probe.txt 2>&1; echo "ingest probe rc=$?"
   timeout -k 10 200 python tools/stage_latency.py > $OUT/stage_latency.txt 2>&1; echo "stage latency rc=$?"
   timeout -k 10 200 python tools/latency_probe.py > $OUT/latency_probe.txt 2>&1; echo "latency probe rc=$?"
-  timeout -k 10 500 python tools/soak.py 200 > $OUT/soak.txt 2>&1; echo "soak rc=$?"; tail -8 $OUT/soak.txt
+  timeout -k 10 900 python tools/soak.py 2000 > $OUT/soak.txt 2>&1; echo "soak rc=$?"; tail -8 $OUT/soak.txt
 fi
 python - <<PY
 import json,glob

@@ -18,6 +18,9 @@ CASES = [
     ("c2", 640, 480, 32, dict(levels=8, cell=8, min_arc=9, max_features=2000), dict(mode=1, window=-1, md=64, stride=1)),
     # 71 pairs x 4 query tiles >= 256 work items: the size rule takes match_tile_kernel (LDS ring, one barrier per step)
     ("c2_tile", 640, 480, 72, dict(levels=8, cell=8, min_arc=9, max_features=2000), dict(mode=1, window=-1, md=64, stride=1)),
+    # 2048 frames (32 distinct ones, repeated): the launch sizes at which detect runs in groups of four tiles per workgroup
+    # and the tile matcher covers the chip for 16 rounds of workgroups; a quarter of the iterations
+    ("c2_bench", 640, 480, 2048, dict(levels=8, cell=8, min_arc=9, max_features=2000), dict(mode=1, window=-1, md=64, stride=1, div=4, distinct=32)),
     ("c3", 848, 480, 32, dict(levels=8, cell=8, min_arc=9, max_features=2000), dict(mode=1, window=16, md=80, stride=2)),
     ("ref", 640, 480, 32, dict(), dict(mode=0, window=32, md=8, stride=1)),
     ("c5", 3840, 2160, 2, dict(levels=12, cell=16, min_arc=9, max_features=8000), dict(mode=1, window=-1, md=64, stride=1)),
@@ -31,20 +34,22 @@ for name, w, h, B, cfg, mm in CASES:
     ctx = orbfe.Context(w, h, max_batch=B, **cfg)
     cap = ctx.cap
     scale = (w * h) // (640 * 480)
-    frames = np.stack([synth.frame(w, h, 100 + i, "rects", n_rects=800 * scale, min_size=6, max_size=32) for i in range(B)])
-    d_in = torch.from_numpy(frames.reshape(-1)).cuda()
+    nd = mm.get("distinct", B)
+    frames = np.stack([synth.frame(w, h, 100 + i, "rects", n_rects=800 * scale, min_size=6, max_size=32) for i in range(nd)])
+    d_in = torch.from_numpy(frames).cuda()[torch.arange(B, device="cuda") % nd].reshape(-1).contiguous()
+    n_it = max(iters // mm.get("div", 1), 2)
     rec = torch.zeros(B * cap * 52, dtype=torch.uint8, device="cuda")
     cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
     n_pairs = (B - 1) if mm["stride"] == 1 else B // 2
     idx = torch.zeros(n_pairs * cap, dtype=torch.int32, device="cuda")
     dist = torch.zeros(n_pairs * cap, dtype=torch.int32, device="cuda")
     first = None
-    for it in range(iters):
+    wts = torch.arange(1, rec.numel() + 1, device="cuda", dtype=torch.int64) % 65521
+    for it in range(n_it):
         rec.zero_()
         ctx.extract(d_in.data_ptr(), w, w * h, B, rec.data_ptr(), cnt.data_ptr(), None, s)
         ctx.match_pairs(rec.data_ptr(), cnt.data_ptr(), B, 0, mm["stride"], mm["mode"], mm["window"], mm["md"],
                         idx.data_ptr(), dist.data_ptr(), s)
-        wts = torch.arange(1, rec.numel() + 1, device="cuda", dtype=torch.int64) % 65521
         sig = (int((rec.to(torch.int64) * wts).sum()), int(cnt.sum()), int((idx.to(torch.int64) * 31 + dist).sum()))
         if first is None:
             first = sig
@@ -52,7 +57,7 @@ for name, w, h, B, cfg, mm in CASES:
             bad += 1
             print("MISMATCH", name, it, sig, first)
             break
-    print("%s: %d iterations, keypoints %d, matches %d, signature %s" % (name, iters, first[1], int((idx >= 0).sum()), "repeats" if bad == 0 else "CHANGED"))
+    print("%s: %d iterations, keypoints %d, matches %d, signature %s" % (name, n_it, first[1], int((idx >= 0).sum()), "repeats" if bad == 0 else "CHANGED"))
 # align_depth_to_other (r4): LDS-window + global atomicMin splat, both output protocols, pipelined launches
 import ctypes as C  # noqa: E402
 w, h, B = 848, 480, 24
