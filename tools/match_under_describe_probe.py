@@ -96,3 +96,4 @@ def bench(B, steps):
 
 bench(256, 200)
 bench(1024, 60)
+bench(4096, 20)
